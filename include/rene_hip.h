@@ -1,0 +1,285 @@
+/*
+ * rene_hip.h -- C ABI of the MI355X-native render path for hatoo/rene.
+ *
+ * The reference (Rust + Vulkan-RT) has no FFI seam of its own: the render path is inlined in
+ * `main()` (rene/src/main.rs:209-1687).  The natural seam, and the one this library implements, is
+ *
+ *     flat `Scene` tables in  (rene/src/scene.rs:36-49, consumed by
+ *                              SceneBuffers::new, rene/src/main.rs:2910-3336)
+ *     3 accumulation layers out (RGBA32F array image, rene/src/main.rs:383-408,
+ *                              read back at rene/src/main.rs:1453-1623)
+ *
+ * Every struct below is a plain-old-data restatement of one reference table; the comment on each
+ * names the reference type it replaces.  No C++ / torch / HIP types appear in any signature, so a
+ * Rust host binds this with `extern "C"` + `#[repr(C)]` (see INTEGRATION.md for the stub).
+ *
+ * Conventions: all matrices are column-major f32 (glam `Mat4::to_cols_array`, `Affine3A` as
+ * x_axis,y_axis,z_axis,translation); all indices are u32; every function returns 0 on success and
+ * a negative `rene_status` otherwise, with a thread-local message behind `rene_last_error()`.
+ * Nothing in this library aborts or throws across the boundary (the reference `unwrap()`s every
+ * Vulkan call, rene/src/main.rs passim).
+ */
+#ifndef RENE_HIP_H
+#define RENE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RENE_ABI_VERSION 1u
+
+typedef enum rene_status {
+  RENE_OK = 0,
+  RENE_ERR_INVALID_ARGUMENT = -1,
+  RENE_ERR_INVALID_SCENE = -2,
+  RENE_ERR_DEVICE = -3,          /* a HIP call failed; message carries hipGetErrorString */
+  RENE_ERR_UNSUPPORTED = -4,     /* e.g. Integrator "volpath" (not built yet) */
+  RENE_ERR_OUT_OF_MEMORY = -5,
+  RENE_ERR_IO = -6,
+  RENE_ERR_PARSE = -7
+} rene_status;
+
+/* ---- enumerations; numeric values equal the reference's #[repr(u32)] discriminants ---------- */
+
+/* ShaderOffset, rene/src/main.rs:41-45 */
+enum { RENE_SHAPE_TRIANGLE = 0, RENE_SHAPE_SPHERE = 1 };
+/* MaterialType, rene-shader/src/material.rs:52-63 */
+enum {
+  RENE_MATERIAL_NONE = 0, RENE_MATERIAL_MATTE = 1, RENE_MATERIAL_GLASS = 2,
+  RENE_MATERIAL_SUBSTRATE = 3, RENE_MATERIAL_METAL = 4, RENE_MATERIAL_MIRROR = 5,
+  RENE_MATERIAL_UBER = 6, RENE_MATERIAL_PLASTIC = 7
+};
+/* TextureType, rene-shader/src/texture.rs:22-29 */
+enum { RENE_TEXTURE_SOLID = 0, RENE_TEXTURE_CHECKERBOARD = 1, RENE_TEXTURE_IMAGEMAP = 2,
+       RENE_TEXTURE_SCALE = 3 };
+/* AreaLightType, rene-shader/src/area_light.rs:9-13 */
+enum { RENE_AREA_LIGHT_NULL = 0, RENE_AREA_LIGHT_DIFFUSE = 1 };
+/* LightType, rene-shader/src/light.rs:19-21 */
+enum { RENE_LIGHT_DISTANT = 0 };
+/* Integrator, rene/src/scene/intermediate_scene.rs:186-190 */
+enum { RENE_INTEGRATOR_PATH = 0, RENE_INTEGRATOR_VOLPATH = 1 };
+/* accumulation layers, rene-shader/src/lib.rs:165-172, 210, 226, 230-231 */
+enum { RENE_LAYER_RADIANCE = 0, RENE_LAYER_NORMAL = 1, RENE_LAYER_ALBEDO = 2, RENE_LAYER_COUNT = 3 };
+
+/* ---- scene tables ---------------------------------------------------------------------------- */
+
+/* Vertex, rene-shader/src/lib.rs:883-890 (position, normal, uv); packed to 32 B here (the
+ * reference's Vec3A padding carries no information). */
+typedef struct rene_vertex {
+  float position[3];
+  float normal[3];
+  float uv[2];
+} rene_vertex;
+
+/* TriangleMesh, rene/src/scene/intermediate_scene.rs:149-153.  Indices are mesh-local; the
+ * library rebases them the way SceneBuffers::new does (rene/src/main.rs:2943-2963). */
+typedef struct rene_mesh {
+  const rene_vertex* vertices;
+  const uint32_t* indices;
+  uint32_t n_vertices;
+  uint32_t n_indices; /* multiple of 3 */
+} rene_mesh;
+
+/* TlasInstance, rene/src/scene.rs:25-34.  `matrix` is the Affine3A object-to-world transform
+ * (for spheres already multiplied by scale(radius), rene/src/scene.rs:418-423). */
+typedef struct rene_instance {
+  uint32_t shape;           /* RENE_SHAPE_* */
+  int32_t mesh_index;       /* blas_index; -1 for spheres */
+  uint32_t material_index;
+  uint32_t area_light_index;
+  uint32_t interior_medium_index;
+  uint32_t exterior_medium_index;
+  float matrix[12];         /* x_axis, y_axis, z_axis, translation */
+} rene_instance;
+
+/* EnumMaterial, rene-shader/src/material.rs:43-70.  Field use per type follows the reference's
+ * `new_data` constructors (material.rs:107-115, 138-152, 228-242, 319-326, 353-360, 495-517,
+ * 642-657). */
+typedef struct rene_material {
+  uint32_t type;
+  uint32_t u0[4];
+  uint32_t u1[4];
+  float v0[4];
+} rene_material;
+
+/* EnumTexture, rene-shader/src/texture.rs:14-36; field use per texture.rs:62-96. */
+typedef struct rene_texture {
+  uint32_t type;
+  uint32_t u0[4];
+  float v0[4];
+} rene_texture;
+
+/* EnumAreaLight, rene-shader/src/area_light.rs:21-33 */
+typedef struct rene_area_light {
+  uint32_t type;
+  float v0[4]; /* L.rgb, 0 */
+} rene_area_light;
+
+/* EnumLight, rene-shader/src/light.rs:8-28.  Distant: v0 = normalize(from - to), v1 = L
+ * (light.rs:43-50). */
+typedef struct rene_light {
+  uint32_t type;
+  float v0[4];
+  float v1[4];
+} rene_light;
+
+/* Image, rene/src/scene/image.rs:1-19: linear RGBA32F, row 0 first. */
+typedef struct rene_image {
+  const float* rgba;
+  uint32_t width;
+  uint32_t height;
+} rene_image;
+
+/* Uniform, rene-shader/src/lib.rs:90-102.  `projection_inv` is PerspectiveCamera.projection, i.e.
+ * Mat4::perspective_lh(fov, aspect, 0.01, 1000).inverse() (rene/src/scene.rs:163-164);
+ * lights_len / emit_object_len / emit_primitives are derived by the library
+ * (rene/src/scene.rs:166, rene/src/main.rs:3278-3280). */
+typedef struct rene_uniform {
+  float camera_to_world[16];
+  float background_matrix[16];
+  float background_color[4];
+  float projection_inv[16];
+  uint32_t background_texture;
+} rene_uniform;
+
+/* Scene, rene/src/scene.rs:36-49 (+ Film, intermediate_scene.rs:155-160).  All pointers are
+ * borrowed for the duration of the call they are passed to. */
+typedef struct rene_scene_desc {
+  uint32_t struct_size;   /* sizeof(rene_scene_desc), ABI guard */
+  uint32_t integrator;    /* RENE_INTEGRATOR_* */
+  uint32_t xresolution;
+  uint32_t yresolution;
+  rene_uniform uniform;
+  uint32_t n_instances;
+  uint32_t n_meshes;
+  uint32_t n_materials;
+  uint32_t n_textures;
+  uint32_t n_area_lights;
+  uint32_t n_lights;
+  uint32_t n_images;
+  const rene_instance* instances;
+  const rene_mesh* meshes;
+  const rene_material* materials;   /* [0] is the None sentinel, rene/src/scene.rs:109 */
+  const rene_texture* textures;     /* [0] is solid white, rene/src/scene.rs:113-116 */
+  const rene_area_light* area_lights; /* [0] is the Null sentinel, rene/src/scene.rs:110 */
+  const rene_light* lights;
+  const rene_image* images;
+} rene_scene_desc;
+
+/* ---- render options (additive; the reference hard-codes these, rene/src/main.rs:77-81, 1301) - */
+
+#define RENE_DEFAULT_SEED 0x52454E45u /* "RENE" */
+#define RENE_TILE_SIZE 32u
+
+enum {
+  RENE_FLAG_COUNTERS = 1u << 0, /* also count BVH node visits / primitive tests (slower kernel) */
+  RENE_FLAG_NO_AOV = 1u << 1    /* skip layers 1-2 (first-hit normal/albedo) */
+};
+enum { RENE_SHARD_TILES = 0, RENE_SHARD_FRAMES = 1 };
+
+typedef struct rene_opts {
+  uint32_t struct_size;  /* sizeof(rene_opts) */
+  uint32_t seed;         /* master seed; frame k uses the k-th next_u32() of PCG32si::new(seed) */
+  int32_t device;        /* HIP device ordinal */
+  uint32_t flags;        /* RENE_FLAG_* */
+  uint32_t shard_mode;   /* RENE_SHARD_* */
+  uint32_t shard_rank;   /* this context renders tiles (or frames) with index % shard_count == shard_rank */
+  uint32_t shard_count;  /* 0 or 1 = unsharded */
+  uint32_t reserved;
+  void* framebuffer;     /* optional caller-owned DEVICE buffer of 3*yres*xres*4 floats, else NULL */
+  void* stream;          /* optional hipStream_t to launch on, else NULL (library-owned stream) */
+} rene_opts;
+
+/* Device counters; a "ray" is one traversal query (SURVEY section 8 d). */
+typedef struct rene_stats {
+  uint64_t rays_closest;  /* rene-shader/src/lib.rs:195-207 */
+  uint64_t rays_shadow;   /* lib.rs:245-258 */
+  uint64_t rays_emitter;  /* lib.rs:301-314 */
+  uint64_t paths;         /* raygen invocations */
+  uint64_t bounces;       /* loop iterations that shaded a hit (path-state round trips) */
+  uint64_t hits;          /* closest hits shaded */
+  uint64_t adds;          /* add_image calls, lib.rs:165-172 */
+  uint64_t node_visits;   /* only with RENE_FLAG_COUNTERS */
+  uint64_t prim_tests;    /* only with RENE_FLAG_COUNTERS */
+  uint64_t frames;        /* frames rendered so far (per context) */
+  uint64_t launches;      /* kernel launches so far */
+  double kernel_ms;       /* sum of HIP-event durations of those launches */
+  double last_launch_ms;
+} rene_stats;
+
+/* One closest-hit record (what Vulkan traversal hands the hit shaders: t, instance, primitive,
+ * barycentrics; rene-shader/src/lib.rs:892-905). */
+typedef struct rene_hit {
+  float t;               /* < 0: miss */
+  float u, v;
+  uint32_t instance;
+  uint32_t primitive;
+} rene_hit;
+
+typedef struct rene_ctx rene_ctx;
+
+/* ---- render path ----------------------------------------------------------------------------- */
+
+/* Replaces SceneBuffers::new + pipeline/SBT/descriptor setup (rene/src/main.rs:513-1199): flatten,
+ * build the BVHs, upload, clear the accumulation image (main.rs:1229-1237). */
+int rene_create(const rene_scene_desc* scene, const rene_opts* opts, rene_ctx** out);
+
+/* Replaces the trace loop (rene/src/main.rs:1315-1397): render frames
+ * [first_frame, first_frame + n_frames) and add them into the accumulation layers.  Asynchronous
+ * on the context's stream; ordered with later calls on the same context. */
+int rene_render(rene_ctx* ctx, uint32_t first_frame, uint32_t n_frames);
+
+/* Waits for everything queued on the context (queue_wait_idle, main.rs:1389). */
+int rene_sync(rene_ctx* ctx);
+
+/* Replaces layer readback + f32_4_to_3 (main.rs:1453-1619): copies layer `layer` as tightly packed
+ * RGB (channels == 3) or RGBA (channels == 4) f32 rows, top row first, un-averaged sums. */
+int rene_download(rene_ctx* ctx, int layer, int channels, float* dst, size_t dst_floats);
+
+/* Zero the accumulation layers and the counters (main.rs:1229-1237). */
+int rene_reset(rene_ctx* ctx);
+
+/* Device address of the accumulation image [3][yres][xres][4] f32 (for an RCCL reduce by the host). */
+int rene_framebuffer(rene_ctx* ctx, void** device_ptr, size_t* n_floats);
+
+int rene_get_stats(rene_ctx* ctx, rene_stats* out);
+
+/* Batch closest-hit queries against the main (which == 0) or emitter-only (which == 1) structure;
+ * host pointers.  Exposes the traversal the Vulkan driver hides. */
+int rene_trace(rene_ctx* ctx, int which, size_t n, const float* origins, const float* directions,
+               float tmin, float tmax, rene_hit* out);
+
+void rene_destroy(rene_ctx* ctx);
+
+const char* rene_last_error(void);
+uint32_t rene_abi_version(void);
+
+/* ---- output transform (rene/src/main.rs:1758-1810); pure host functions ----------------------- */
+
+/* average (main.rs:1758-1764) then to_rgb8 (main.rs:1785-1792) */
+void rene_to_rgb8(const float* sums, size_t n_floats, uint32_t n_samples, uint8_t* out);
+/* to_aov / to_aov_normal (main.rs:1794-1810) after average */
+void rene_to_aov8(const float* sums, size_t n_floats, uint32_t n_samples, int is_normal, uint8_t* out);
+/* The build-defined seed schedule (SURVEY section 8 d): out[k] = frame seed of frame first+k. */
+void rene_frame_seeds(uint32_t master_seed, uint32_t first_frame, uint32_t n, uint32_t* out);
+
+/* ---- caller side: pbrt-v3 loader (pbrt-parser/src/lib.rs, rene/src/scene.rs) ------------------ */
+
+typedef struct rene_scene rene_scene;
+
+/* expand_include + parse_pbrt + Scene::create (rene/src/main.rs:107-205). */
+int rene_scene_load_pbrt(const char* path, rene_scene** out);
+/* same, from memory; base_dir resolves Include / plymesh / imagemap paths */
+int rene_scene_parse_pbrt(const char* text, const char* base_dir, rene_scene** out);
+const rene_scene_desc* rene_scene_get_desc(const rene_scene* scene);
+/* Film filename (intermediate_scene.rs:155-170) */
+const char* rene_scene_film_filename(const rene_scene* scene);
+void rene_scene_free(rene_scene* scene);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RENE_HIP_H */

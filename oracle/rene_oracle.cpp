@@ -1,0 +1,1560 @@
+// oracle/rene_oracle.cpp -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+//
+// CPU restatement of hatoo/rene's path-tracing arithmetic (rene-shader/src/**), used only as the
+// parity checker (tests/, __graft_entry__.smoke()) and as the `cpu_baseline` leg of bench.py.
+// Nothing under rene_amd/ may include, link or call this file.
+//
+// Parity status: **UNPINNED**.  The reference ships no test, golden vector or fixture for the
+// render path (its only tests are 10 parser tests), cannot be built here (no
+// Rust toolchain, needs a Vulkan-RT GPU), and seeds its frames from entropy
+// (rene/src/main.rs:1301).  What pins this file is therefore (i) integer-exact known answers for
+// PCG32si restated from rand.rs, (ii) closed-form checks of each BxDF, and (iii) a statistical
+// comparison of a full render with rene's own published PNG (images/cornell-box.png) done by
+// tests/ when /root/reference is present.
+//
+// Every function cites the reference lines it follows (paths relative to /root/reference).
+// Arithmetic is plain fp32, compiled with -ffp-contract=off so that no FMA is introduced (Rust
+// never contracts).  Traversal + ray/triangle intersection live in the Vulkan driver in the
+// reference (ash 0.36.0+1.3.206, call sites rene-shader/src/lib.rs:195-207, 245-258, 301-314);
+// here they are a two-level BVH2 (TLAS over instances, BLAS per mesh, rays transformed into object
+// space exactly like VK_KHR_ray_tracing does) with a Moeller-Trumbore test, no culling, closest
+// hit wins, tmin <= t <= tmax.
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../include/rene_hip.h"
+
+namespace {
+
+constexpr float PI = 3.14159265358979323846f;
+constexpr float FRAC_1_PI = 0.318309886183790671538f;
+constexpr float TAU = 6.28318530717958647692f;
+
+// ---- glam::Vec3A subset ------------------------------------------------------------------------
+struct V3 {
+  float x, y, z;
+};
+inline V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+inline V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 operator-(V3 a) { return {-a.x, -a.y, -a.z}; }
+inline V3 operator*(V3 a, V3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+inline V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+inline V3 operator*(float s, V3 a) { return {a.x * s, a.y * s, a.z * s}; }
+inline V3 operator/(V3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+inline V3 operator/(V3 a, V3 b) { return {a.x / b.x, a.y / b.y, a.z / b.z}; }
+inline V3& operator+=(V3& a, V3 b) { a = a + b; return a; }
+inline V3& operator*=(V3& a, V3 b) { a = a * b; return a; }
+inline V3& operator*=(V3& a, float s) { a = a * s; return a; }
+inline V3& operator/=(V3& a, float s) { a = a / s; return a; }
+inline bool operator==(V3 a, V3 b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
+inline bool operator!=(V3 a, V3 b) { return !(a == b); }
+inline float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline V3 cross(V3 a, V3 b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+inline float length_squared(V3 a) { return dot(a, a); }
+inline float length(V3 a) { return std::sqrt(dot(a, a)); }
+inline V3 normalize(V3 a) { return a / length(a); }
+inline float max_element(V3 a) { return std::max(a.x, std::max(a.y, a.z)); }
+const V3 ZERO3 = {0.f, 0.f, 0.f};
+const V3 ONE3 = {1.f, 1.f, 1.f};
+
+struct V2 {
+  float x, y;
+};
+
+// Affine 3x4, column vectors x,y,z,w (rene-shader/src/lib.rs:841-850, glam Affine3A)
+struct Affine {
+  V3 x, y, z, w;
+};
+inline V3 transform_point(const Affine& m, V3 p) { return p.x * m.x + p.y * m.y + p.z * m.z + m.w; }
+inline V3 transform_vector(const Affine& m, V3 v) { return v.x * m.x + v.y * m.y + v.z * m.z; }
+
+Affine affine_from12(const float* f) {
+  return Affine{{f[0], f[1], f[2]}, {f[3], f[4], f[5]}, {f[6], f[7], f[8]}, {f[9], f[10], f[11]}};
+}
+// inverse of an affine transform; in double, rounded once (the reference gets world_to_object from
+// the Vulkan driver, rene-shader/src/lib.rs:856, 898)
+Affine affine_inverse(const Affine& m) {
+  double a[3][3] = {{m.x.x, m.y.x, m.z.x}, {m.x.y, m.y.y, m.z.y}, {m.x.z, m.y.z, m.z.z}};
+  double det = a[0][0] * (a[1][1] * a[2][2] - a[1][2] * a[2][1]) -
+               a[0][1] * (a[1][0] * a[2][2] - a[1][2] * a[2][0]) +
+               a[0][2] * (a[1][0] * a[2][1] - a[1][1] * a[2][0]);
+  double id = 1.0 / det;
+  double inv[3][3];
+  inv[0][0] = (a[1][1] * a[2][2] - a[1][2] * a[2][1]) * id;
+  inv[0][1] = (a[0][2] * a[2][1] - a[0][1] * a[2][2]) * id;
+  inv[0][2] = (a[0][1] * a[1][2] - a[0][2] * a[1][1]) * id;
+  inv[1][0] = (a[1][2] * a[2][0] - a[1][0] * a[2][2]) * id;
+  inv[1][1] = (a[0][0] * a[2][2] - a[0][2] * a[2][0]) * id;
+  inv[1][2] = (a[0][2] * a[1][0] - a[0][0] * a[1][2]) * id;
+  inv[2][0] = (a[1][0] * a[2][1] - a[1][1] * a[2][0]) * id;
+  inv[2][1] = (a[0][1] * a[2][0] - a[0][0] * a[2][1]) * id;
+  inv[2][2] = (a[0][0] * a[1][1] - a[0][1] * a[1][0]) * id;
+  double t[3] = {m.w.x, m.w.y, m.w.z};
+  double it[3];
+  for (int r = 0; r < 3; ++r) it[r] = -(inv[r][0] * t[0] + inv[r][1] * t[1] + inv[r][2] * t[2]);
+  Affine o;
+  o.x = {(float)inv[0][0], (float)inv[1][0], (float)inv[2][0]};
+  o.y = {(float)inv[0][1], (float)inv[1][1], (float)inv[2][1]};
+  o.z = {(float)inv[0][2], (float)inv[1][2], (float)inv[2][2]};
+  o.w = {(float)it[0], (float)it[1], (float)it[2]};
+  return o;
+}
+
+// glam Mat4 (column-major) helpers used by the camera and the miss shader
+struct M4 {
+  float m[16];
+};
+// Mat4::transform_point3a: w = 1, no perspective divide (glam 0.20.5 mat4.rs; camera.rs:79-83)
+inline V3 m4_transform_point(const M4& a, V3 p) {
+  return {a.m[0] * p.x + a.m[4] * p.y + a.m[8] * p.z + a.m[12],
+          a.m[1] * p.x + a.m[5] * p.y + a.m[9] * p.z + a.m[13],
+          a.m[2] * p.x + a.m[6] * p.y + a.m[10] * p.z + a.m[14]};
+}
+// Mat4::transform_vector3a: w = 0 (lib.rs:129-131)
+inline V3 m4_transform_vector(const M4& a, V3 p) {
+  return {a.m[0] * p.x + a.m[4] * p.y + a.m[8] * p.z, a.m[1] * p.x + a.m[5] * p.y + a.m[9] * p.z,
+          a.m[2] * p.x + a.m[6] * p.y + a.m[10] * p.z};
+}
+
+// ---- asm.rs shims (GPU semantics: the images rene publishes come from the SPIR-V path) ----------
+// asm.rs:26-46 OpConvertFToU; saturating like Rust `as u32` for the out-of-range cases SPIR-V
+// leaves undefined
+inline uint32_t f32_to_u32(float v) {
+  if (!(v > 0.0f)) return 0u;
+  if (v >= 4294967296.0f) return 0xffffffffu;
+  return (uint32_t)v;
+}
+// asm.rs:54-69 GLSL.std.450 Fract = x - floor(x)
+inline float fract(float v) { return v - std::floor(v); }
+// asm.rs:77-94 GLSL.std.450 FClamp
+inline float f32_clamp(float v, float lo, float hi) { return std::min(std::max(v, lo), hi); }
+
+// ---- rand.rs:4-52 PCG32si ------------------------------------------------------------------------
+struct PCG32si {
+  uint32_t state;
+  void step() { state = state * 747796405u + 2891336453u; }  // rand.rs:12-17
+  static uint32_t output(uint32_t s) {                          // rand.rs:19-22
+    uint32_t word = ((s >> ((s >> 28) + 4u)) ^ s) * 277803737u;
+    return (word >> 22) ^ word;
+  }
+  explicit PCG32si(uint32_t seed) : state(seed) {  // rand.rs:24-30
+    step();
+    state += seed;
+    step();
+  }
+  uint32_t next_u32() {  // rand.rs:32-36
+    uint32_t old = state;
+    step();
+    return output(old);
+  }
+  float next_f32() {  // rand.rs:38-47: (u32 >> 8) * 2^-24
+    uint32_t v = next_u32() >> 8;
+    return (1.0f / 16777216.0f) * (float)v;
+  }
+  float next_f32_range(float lo, float hi) { return lo + (hi - lo) * next_f32(); }  // rand.rs:49-51
+};
+
+// ---- math.rs ---------------------------------------------------------------------------------------
+V3 random_in_unit_sphere(PCG32si& rng) {  // math.rs:8-20
+  for (;;) {
+    float a = rng.next_f32_range(-1.f, 1.f);
+    float b = rng.next_f32_range(-1.f, 1.f);
+    float c = rng.next_f32_range(-1.f, 1.f);
+    V3 v = v3(a, b, c);
+    if (length_squared(v) < 1.0f) return v;
+  }
+}
+V3 random_cosine_direction(PCG32si& rng) {  // math.rs:45-56
+  float r1 = rng.next_f32();
+  float r2 = rng.next_f32();
+  float z = std::sqrt(1.0f - r2);
+  float phi = 2.0f * PI * r1;
+  float r2_sqrt = std::sqrt(r2);
+  float x = std::cos(phi) * r2_sqrt;
+  float y = std::sin(phi) * r2_sqrt;
+  return v3(x, y, z);
+}
+V2 sphere_uv(V3 p) {  // math.rs:70-76
+  float theta = std::acos(p.z);
+  float phi = std::atan2(p.y, p.x);
+  if (phi < 0.0f) phi = phi + 2.0f * PI;
+  return V2{phi * 0.5f * FRAC_1_PI, (theta - PI) * -FRAC_1_PI};
+}
+void coordinate_system(V3 v1, V3& v2, V3& v3o) {  // math.rs:89-97
+  if (std::fabs(v1.x) > std::fabs(v1.y))
+    v2 = v3(-v1.z, 0.f, v1.x) / std::sqrt(v1.x * v1.x + v1.z * v1.z);
+  else
+    v2 = v3(0.f, v1.z, -v1.y) / std::sqrt(v1.y * v1.y + v1.z * v1.z);
+  v3o = cross(v1, v2);
+}
+
+// ---- reflection/onb.rs ----------------------------------------------------------------------------
+struct Onb {
+  V3 u, v, w;
+  static Onb from_w(V3 w) {  // onb.rs:14-18
+    Onb o;
+    o.w = w;
+    coordinate_system(w, o.u, o.v);
+    return o;
+  }
+  V3 local_to_world(V3 a) const { return a.x * u + a.y * v + a.z * w; }          // onb.rs:20-22
+  V3 world_to_local(V3 a) const { return v3(dot(a, u), dot(a, v), dot(a, w)); }  // onb.rs:24-26
+};
+inline float cos_theta(V3 w) { return w.z; }
+inline float cos2_theta(V3 w) { return w.z * w.z; }
+inline float abs_cos_theta(V3 w) { return std::fabs(w.z); }
+inline float sin2_theta(V3 w) { return std::max(1.0f - cos2_theta(w), 0.0f); }  // onb.rs:40-42
+inline float sin_theta(V3 w) { return std::sqrt(sin2_theta(w)); }
+inline float tan_theta(V3 w) { return sin_theta(w) / cos_theta(w); }
+inline float tan2_theta(V3 w) { return sin2_theta(w) / cos2_theta(w); }
+inline float cos_phi(V3 w) {  // onb.rs:56-63
+  float s = sin_theta(w);
+  return s == 0.0f ? 1.0f : f32_clamp(w.x / s, -1.f, 1.f);
+}
+inline float sin_phi(V3 w) {  // onb.rs:65-72
+  float s = sin_theta(w);
+  return s == 0.0f ? 0.0f : f32_clamp(w.y / s, -1.f, 1.f);
+}
+inline float cos2_phi(V3 w) { float c = cos_phi(w); return c * c; }
+inline float sin2_phi(V3 w) { float s = sin_phi(w); return s * s; }
+inline bool same_hemisphere(V3 a, V3 b) { return a.z * b.z > 0.0f; }  // onb.rs:84-86
+
+// ---- reflection/fresnel.rs ------------------------------------------------------------------------
+float fr_dielectric(float cos_theta_i, float eta_i, float eta_t) {  // bxdf.rs:138-165
+  cos_theta_i = f32_clamp(cos_theta_i, -1.f, 1.f);
+  bool entering = cos_theta_i > 0.0f;
+  if (!entering) std::swap(eta_i, eta_t);
+  cos_theta_i = std::fabs(cos_theta_i);
+  float sin_theta_i = std::sqrt(1.0f - cos_theta_i * cos_theta_i);
+  float sin_theta_t = eta_i / eta_t * sin_theta_i;
+  if (sin_theta_t >= 1.0f) return 1.0f;
+  float cos_theta_t = std::sqrt(1.0f - sin_theta_t * sin_theta_t);
+  float r_parl = ((eta_t * cos_theta_i) - (eta_i * cos_theta_t)) /
+                 ((eta_t * cos_theta_i) + (eta_i * cos_theta_t));
+  float r_perp = ((eta_i * cos_theta_i) - (eta_t * cos_theta_t)) /
+                 ((eta_i * cos_theta_i) + (eta_t * cos_theta_t));
+  return 0.5f * (r_parl * r_parl + r_perp * r_perp);
+}
+inline V3 sqrt3(V3 a) { return v3(std::sqrt(a.x), std::sqrt(a.y), std::sqrt(a.z)); }
+V3 fr_conductor(float cos_theta_i, V3 eta_i, V3 eta_t, V3 k) {  // fresnel.rs:78-102
+  cos_theta_i = f32_clamp(cos_theta_i, -1.f, 1.f);
+  V3 eta = eta_t / eta_i;
+  V3 eta_k = k / eta_i;
+  float cos_theta_i2 = cos_theta_i * cos_theta_i;
+  float sin_theta_i2 = 1.0f - cos_theta_i2;
+  V3 eta2 = eta * eta;
+  V3 eta_k2 = eta_k * eta_k;
+  V3 t0 = eta2 - eta_k2 - v3(sin_theta_i2, sin_theta_i2, sin_theta_i2);
+  V3 a2plusb2 = sqrt3(t0 * t0 + 4.0f * eta2 * eta_k2);
+  V3 t1 = a2plusb2 + v3(cos_theta_i2, cos_theta_i2, cos_theta_i2);
+  V3 a = sqrt3(0.5f * (a2plusb2 + t0));
+  V3 t2 = 2.0f * cos_theta_i * a;
+  V3 rs = (t1 - t2) / (t1 + t2);
+  float s4 = sin_theta_i2 * sin_theta_i2;
+  V3 t3 = cos_theta_i2 * a2plusb2 + v3(s4, s4, s4);
+  V3 t4 = t2 * sin_theta_i2;
+  V3 rp = rs * (t3 - t4) / (t3 + t4);
+  return 0.5f * (rp + rs);
+}
+enum FresnelType { FR_CONDUCTOR = 0, FR_NOOP = 1, FR_DIELECTRIC = 2 };  // fresnel.rs:14-20
+struct Fresnel {
+  int type = FR_CONDUCTOR;
+  V3 eta_i = ZERO3, eta_t = ZERO3, k = ZERO3;  // dielectric: eta_i.x, eta_i.y (fresnel.rs:125-138)
+  V3 evaluate(float cos_i) const {              // fresnel.rs:160-171
+    switch (type) {
+      case FR_NOOP: return ONE3;
+      case FR_CONDUCTOR: return fr_conductor(std::fabs(cos_i), eta_i, eta_t, k);  // fresnel.rs:104-108
+      default: {
+        float x = fr_dielectric(cos_i, eta_i.x, eta_i.y);  // fresnel.rs:127-145
+        return v3(x, x, x);
+      }
+    }
+  }
+  static Fresnel conductor(V3 ei, V3 et, V3 kk) { Fresnel f; f.type = FR_CONDUCTOR; f.eta_i = ei; f.eta_t = et; f.k = kk; return f; }
+  static Fresnel nop() { Fresnel f; f.type = FR_NOOP; return f; }
+  static Fresnel dielectric(float ei, float et) { Fresnel f; f.type = FR_DIELECTRIC; f.eta_i = v3(ei, et, 0.f); return f; }
+};
+
+// ---- reflection/microfacet.rs -- TrowbridgeReitz ------------------------------------------------------
+float roughness_to_alpha(float roughness) {  // microfacet.rs:65-74
+  roughness = std::max(roughness, 1e-3f);
+  float x = std::log(roughness);
+  return 1.62142f + 0.819955f * x + 0.1734f * x * x + 0.0171201f * x * x * x +
+         0.000640711f * x * x * x * x;
+}
+V2 trowbridge_reitz_sample11(float cos_theta_, PCG32si& rng) {  // microfacet.rs:77-122
+  float u1 = rng.next_f32();
+  float u2 = rng.next_f32();
+  if (cos_theta_ > 0.9999f) {
+    float r = std::sqrt(u1 / (1.0f - u1));
+    float phi = TAU * u2;
+    return V2{r * std::cos(phi), r * std::sin(phi)};
+  }
+  float sin_theta_ = std::sqrt(std::max(1.0f - cos_theta_ * cos_theta_, 0.0f));
+  float tan_theta_ = sin_theta_ / cos_theta_;
+  float a0 = 1.0f / tan_theta_;
+  float g1 = 2.0f / (1.0f + (1.0f + 1.0f / std::sqrt(a0 * a0)));  // Q11: rene's form, microfacet.rs:91
+  float a = 2.0f * u1 / g1 - 1.0f;
+  float tmp = std::min(1.0f / (a * a - 1.0f), 1e10f);
+  float b = tan_theta_;
+  float d = std::sqrt(std::max(b * b * tmp * tmp - (a * a - b * b) * tmp, 0.0f));
+  float slope_x_1 = b * tmp - d;
+  float slope_x_2 = b * tmp + d;
+  float slope_x = (a < 0.0f || slope_x_2 > a0) ? slope_x_1 : slope_x_2;
+  float s;
+  if (u2 > 0.5f) {
+    s = 1.0f;
+    u2 = 2.0f * (u2 - 0.5f);
+  } else {
+    s = -1.0f;
+    u2 = 2.0f * (0.5f - u2);
+  }
+  float z = (u2 * (u2 * (u2 * 0.27385f - 0.73369f) + 0.46341f)) /
+            (u2 * (u2 * (u2 * 0.093073f + 0.309420f) - 1.000000f) + 0.597999f);
+  float slope_y = s * z * std::sqrt(1.0f + slope_x * slope_x);
+  return V2{slope_x, slope_y};
+}
+V3 trowbridge_reitz_sample(V3 wi, float alpha_x, float alpha_y, PCG32si& rng) {  // microfacet.rs:124-138
+  V3 wi_stretched = normalize(v3(alpha_x * wi.x, alpha_y * wi.y, wi.z));
+  V2 slope = trowbridge_reitz_sample11(cos_theta(wi_stretched), rng);
+  float slope_x = cos_phi(wi_stretched) * slope.x - sin_phi(wi_stretched) * slope.y;
+  float slope_y = sin_phi(wi_stretched) * slope.x + cos_phi(wi_stretched) * slope.y;
+  slope_x = alpha_x * slope_x;
+  slope_y = alpha_y * slope_y;
+  return normalize(v3(-slope_x, -slope_y, 1.0f));
+}
+struct TrowbridgeReitz {
+  float alpha_x = 0.f, alpha_y = 0.f;
+  float d(V3 wh) const {  // microfacet.rs:141-155
+    float t2 = tan2_theta(wh);
+    if (std::isinf(t2)) return 0.0f;
+    float c2 = cos2_theta(wh);
+    float cos4 = c2 * c2;
+    float e = (cos2_phi(wh) / (alpha_x * alpha_x) + sin2_phi(wh) / (alpha_y * alpha_y)) * t2;
+    return 1.0f / (PI * alpha_x * alpha_y * cos4 * (1.0f + e) * (1.0f + e));
+  }
+  float lambda(V3 w) const {  // microfacet.rs:157-174 (Q9: Beckmann's rational fit)
+    float abs_tan = std::fabs(tan_theta(w));
+    if (std::isinf(abs_tan)) return 0.0f;
+    float alpha = std::sqrt(cos2_phi(w) * alpha_x * alpha_x + sin2_phi(w) * alpha_y * alpha_y);
+    float a = 1.0f / (alpha * abs_tan);
+    if (a >= 1.6f) return 0.0f;
+    return (1.0f - 1.259f * a + 0.396f * a * a) / (3.535f * a + 2.181f * a * a);
+  }
+  float g(V3 wo, V3 wi) const { return 1.0f / (1.0f + lambda(wo) + lambda(wi)); }  // microfacet.rs:15-17
+  float g1(V3 w) const { return 1.0f / (1.0f + lambda(w)); }                         // microfacet.rs:19-21
+  V3 sample_wh(V3 wo, PCG32si& rng) const {  // microfacet.rs:176-190
+    bool flip = wo.z < 0.0f;
+    V3 wh = trowbridge_reitz_sample(flip ? -wo : wo, alpha_x, alpha_y, rng);
+    return flip ? -wh : wh;
+  }
+  float pdf(V3 wo, V3 wh) const {  // microfacet.rs:192-194
+    return d(wh) * g1(wo) * std::fabs(dot(wo, wh)) / abs_cos_theta(wo);
+  }
+};
+
+// ---- reflection/bxdf.rs ------------------------------------------------------------------------------
+struct SampledF {
+  V3 wi = ZERO3, f = ZERO3;
+  float pdf = 0.0f;
+};
+enum BxdfKind { K_REFLECTION = 1, K_TRANSMISSION = 2, K_DIFFUSE = 4 };  // reflection.rs:66-70
+enum BxdfType {  // reflection.rs:102-111
+  BX_LAMBERT = 0, BX_FRESNEL_SPECULAR, BX_FRESNEL_BLEND, BX_MICROFACET_REFLECTION,
+  BX_SPECULAR_REFLECTION, BX_SPECULAR_TRANSMISSION
+};
+inline V3 reflect(V3 wo, V3 n) { return -wo + 2.0f * dot(wo, n) * n; }  // bxdf.rs:117-119
+bool refract(V3 wi, V3 n, float etai_over_etat, V3& out) {              // bxdf.rs:121-136
+  float cos_theta_i = dot(n, wi);
+  float sin2theta_i = std::max(1.0f - cos_theta_i * cos_theta_i, 0.0f);
+  float sin2theta_t = etai_over_etat * etai_over_etat * sin2theta_i;
+  if (sin2theta_t >= 1.0f) {
+    out = ZERO3;
+    return false;
+  }
+  float cos_theta_t = std::sqrt(1.0f - sin2theta_t);
+  out = etai_over_etat * -wi + (etai_over_etat * cos_theta_i - cos_theta_t) * n;
+  return true;
+}
+inline V3 face_forward(V3 v, V3 v2) { return dot(v, v2) < 0.0f ? -v : v; }  // bxdf.rs:348-354
+
+struct Bxdf {
+  int type = BX_LAMBERT;
+  V3 a = ZERO3;   // v0.xyz: albedo / rd / r / t ; FresnelSpecular: ir in a.x
+  V3 b = ZERO3;   // v1.xyz: rs ; SpecularTransmission: eta_a, eta_b
+  TrowbridgeReitz dist;
+  Fresnel fresnel;
+
+  int kind() const {
+    switch (type) {
+      case BX_LAMBERT: return K_REFLECTION | K_DIFFUSE;               // bxdf.rs:83-85
+      case BX_FRESNEL_SPECULAR: return K_REFLECTION | K_TRANSMISSION;  // bxdf.rs:185-187
+      case BX_FRESNEL_BLEND: return K_REFLECTION | K_DIFFUSE;          // bxdf.rs:262-264
+      case BX_MICROFACET_REFLECTION: return K_REFLECTION | K_DIFFUSE;  // bxdf.rs:357-359 (sic)
+      case BX_SPECULAR_REFLECTION: return K_REFLECTION;                // bxdf.rs:429-431
+      default: return K_TRANSMISSION;                                  // bxdf.rs:473-475
+    }
+  }
+  V3 schlick_fresnel(float cos_t) const {  // bxdf.rs:252-257
+    float v = 1.0f - cos_t;
+    float v5 = (v * v) * (v * v) * v;
+    return b + v5 * (ONE3 - b);
+  }
+  V3 f(V3 wo, V3 wi) const {
+    switch (type) {
+      case BX_LAMBERT: return a * FRAC_1_PI;  // bxdf.rs:87-89
+      case BX_FRESNEL_BLEND: {                // bxdf.rs:266-290
+        auto pow5 = [](float v) { return (v * v) * (v * v) * v; };
+        V3 diffuse = (28.0f / (23.0f * PI)) * a * (ONE3 - b) *
+                     (1.0f - pow5(1.0f - 0.5f * abs_cos_theta(wi))) *
+                     (1.0f - pow5(1.0f - 0.5f * abs_cos_theta(wo)));
+        V3 wh = wi + wo;
+        if (wh == ZERO3) return ZERO3;
+        wh = normalize(wh);
+        V3 specular = dist.d(wh) /
+                      (4.0f * std::fabs(dot(wi, wh)) * std::max(abs_cos_theta(wi), abs_cos_theta(wo))) *
+                      schlick_fresnel(dot(wi, wh));
+        return diffuse + specular;
+      }
+      case BX_MICROFACET_REFLECTION: {  // bxdf.rs:361-381
+        float cos_theta_o = abs_cos_theta(wo);
+        float cos_theta_i = abs_cos_theta(wi);
+        V3 wh = wi + wo;
+        if (cos_theta_i == 0.0f || cos_theta_o == 0.0f || wh == ZERO3) return ZERO3;
+        wh = normalize(wh);
+        V3 fr = fresnel.evaluate(dot(wi, face_forward(wh, v3(0.f, 0.f, 1.f))));
+        return a * dist.d(wh) * dist.g(wo, wi) * fr / (4.0f * cos_theta_i * cos_theta_o);
+      }
+      default: return ZERO3;  // bxdf.rs:189-191, 433-435, 477-479
+    }
+  }
+  float pdf(V3 wo, V3 wi) const {
+    switch (type) {
+      case BX_LAMBERT:  // bxdf.rs:107-113
+        return same_hemisphere(wo, wi) ? abs_cos_theta(wi) * FRAC_1_PI : 0.0f;
+      case BX_FRESNEL_BLEND: {  // bxdf.rs:318-328
+        if (!same_hemisphere(wo, wi)) return 0.0f;
+        V3 wh = normalize(wo + wi);
+        float pdf_wh = dist.pdf(wo, wh);
+        return 0.5f * (abs_cos_theta(wi) * FRAC_1_PI + pdf_wh / (4.0f * dot(wo, wh)));
+      }
+      case BX_MICROFACET_REFLECTION: {  // bxdf.rs:407-414
+        if (!same_hemisphere(wo, wi)) return 0.0f;
+        V3 wh = normalize(wo + wi);
+        return dist.pdf(wo, wh) / (4.0f * dot(wo, wh));
+      }
+      default: return 0.0f;  // bxdf.rs:229-231, 445-447, 514-516
+    }
+  }
+  SampledF sample_f(V3 wo, PCG32si& rng) const {
+    SampledF s;
+    switch (type) {
+      case BX_LAMBERT: {  // bxdf.rs:91-105
+        V3 wi = random_cosine_direction(rng);
+        if (wo.z < 0.0f) wi.z = -wi.z;
+        s.pdf = pdf(wo, wi);
+        s.wi = wi;
+        s.f = f(wo, wi);
+        return s;
+      }
+      case BX_FRESNEL_SPECULAR: {  // bxdf.rs:193-227
+        float ir = a.x;
+        float ct = cos_theta(wo);
+        float fr = fr_dielectric(ct, 1.0f, ir);
+        if (rng.next_f32() < fr) {
+          V3 wi = v3(-wo.x, -wo.y, wo.z);
+          s.wi = wi;
+          s.f = fr * ONE3 / abs_cos_theta(wi);
+          s.pdf = fr;
+          return s;
+        }
+        float eta_i, eta_t;
+        if (cos_theta(wo) > 0.0f) { eta_i = 1.0f; eta_t = ir; } else { eta_i = ir; eta_t = 1.0f; }
+        float refraction_ratio = eta_i / eta_t;
+        V3 wi;
+        bool ok = refract(wo, v3(0.f, 0.f, wo.z > 0.0f ? 1.0f : -1.0f), refraction_ratio, wi);
+        s.wi = wi;
+        s.f = ONE3 * (1.0f - fr) / abs_cos_theta(wi);
+        s.pdf = !ok ? 0.0f : 1.0f - fr;
+        return s;
+      }
+      case BX_FRESNEL_BLEND: {  // bxdf.rs:292-316
+        V3 wi;
+        if (rng.next_f32() < 0.5f) {
+          wi = random_cosine_direction(rng);
+          if (wo.z < 0.0f) wi.z = -wi.z;
+        } else {
+          V3 wh = dist.sample_wh(wo, rng);
+          wi = reflect(wo, wh);
+          if (!same_hemisphere(wo, wi)) return SampledF();
+        }
+        s.wi = wi;
+        s.f = f(wo, wi);
+        s.pdf = pdf(wo, wi);
+        return s;
+      }
+      case BX_MICROFACET_REFLECTION: {  // bxdf.rs:383-405
+        if (wo.z == 0.0f) return SampledF();
+        V3 wh = dist.sample_wh(wo, rng);
+        if (dot(wo, wh) < 0.0f) return SampledF();
+        V3 wi = reflect(wo, wh);
+        if (!same_hemisphere(wo, wi)) return SampledF();
+        s.pdf = dist.pdf(wo, wh) / (4.0f * dot(wo, wh));
+        s.wi = wi;
+        s.f = f(wo, wi);
+        return s;
+      }
+      case BX_SPECULAR_REFLECTION: {  // bxdf.rs:437-443
+        V3 wi = v3(-wo.x, -wo.y, wo.z);
+        s.wi = wi;
+        s.f = fresnel.evaluate(cos_theta(wi)) * a / abs_cos_theta(wi);
+        s.pdf = 1.0f;
+        return s;
+      }
+      default: {  // SpecularTransmission, bxdf.rs:481-512
+        bool entering = cos_theta(wo) > 0.0f;
+        float eta_a = b.x, eta_b = b.y;
+        float eta_i = entering ? eta_a : eta_b;
+        float eta_t = entering ? eta_b : eta_a;
+        V3 wi;
+        bool ok = refract(wo, v3(0.f, 0.f, wo.z > 0.0f ? 1.0f : -1.0f), eta_i / eta_t, wi);
+        if (!ok) return SampledF();
+        float fx = fr_dielectric(cos_theta(wi), eta_a, eta_b);  // "Little optimize", bxdf.rs:456
+        V3 ft = a * (ONE3 - v3(fx, fx, fx));
+        s.wi = wi;
+        s.f = ft / abs_cos_theta(wi);
+        s.pdf = 1.0f;
+        return s;
+      }
+    }
+  }
+};
+
+// ---- reflection.rs:228-343 Bsdf --------------------------------------------------------------------
+struct Bsdf {
+  V3 ng = v3(0.f, 0.f, 1.f);
+  Onb onb;
+  uint32_t len = 0;
+  Bxdf bxdfs[5];
+  void clear(V3 n, const Onb& o) { len = 0; ng = n; onb = o; }  // reflection.rs:250-254
+  Bxdf& add_mut() { return bxdfs[len++]; }                      // reflection.rs:261-265
+  bool contains(int kind) const {                               // reflection.rs:267-282
+    for (uint32_t i = 0; i < len; ++i)
+      if (bxdfs[i].kind() & kind) return true;
+    return false;
+  }
+  V3 f(V3 wo_world, V3 wi_world) const {  // reflection.rs:286-309
+    V3 wi = onb.world_to_local(wi_world);
+    V3 wo = onb.world_to_local(wo_world);
+    if (wo.z == 0.0f) return ZERO3;
+    bool refl = dot(wi_world, ng) * dot(wo_world, ng) > 0.0f;
+    V3 f = ZERO3;
+    for (uint32_t i = 0; i < len; ++i) {
+      int k = bxdfs[i].kind();
+      if ((refl && (k & K_REFLECTION)) || (!refl && (k & K_TRANSMISSION))) f += bxdfs[i].f(wo, wi);
+    }
+    return f;
+  }
+  SampledF sample_f(V3 wo_world, PCG32si& rng) const {  // reflection.rs:311-326
+    if (len == 0) return SampledF();
+    uint32_t index = rng.next_u32() % len;
+    V3 wo = onb.world_to_local(wo_world);
+    SampledF s = bxdfs[index].sample_f(wo, rng);
+    s.pdf /= (float)len;
+    s.wi = onb.local_to_world(s.wi);
+    return s;
+  }
+  float pdf(V3 wo_world, V3 wi_world) const {  // reflection.rs:328-342
+    float p = 0.0f;
+    V3 wo = onb.world_to_local(wo_world);
+    V3 wi = onb.world_to_local(wi_world);
+    for (uint32_t i = 0; i < len; ++i) p += bxdfs[i].pdf(wo, wi);
+    return p / (float)len;
+  }
+};
+
+// ---- scene ---------------------------------------------------------------------------------------
+struct BBox {
+  float lo[3], hi[3];
+  void reset() {
+    for (int i = 0; i < 3; ++i) { lo[i] = std::numeric_limits<float>::infinity(); hi[i] = -lo[i]; }
+  }
+  void grow(const float* p) {
+    for (int i = 0; i < 3; ++i) { lo[i] = std::min(lo[i], p[i]); hi[i] = std::max(hi[i], p[i]); }
+  }
+  void grow(const BBox& b) { grow(b.lo); grow(b.hi); }
+  float half_area() const {
+    float d[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
+    return d[0] * d[1] + d[1] * d[2] + d[2] * d[0];
+  }
+};
+
+// plain BVH2, binned SAH; the oracle's own (the product builds a different, flattened one)
+struct Bvh {
+  struct Node {
+    BBox box;
+    int32_t left = -1, right = -1;  // inner
+    uint32_t first = 0, count = 0;  // leaf when count > 0
+  };
+  std::vector<Node> nodes;
+  std::vector<uint32_t> prim;  // permutation
+
+  void build(const std::vector<BBox>& boxes, uint32_t max_leaf) {
+    nodes.clear();
+    prim.resize(boxes.size());
+    for (size_t i = 0; i < boxes.size(); ++i) prim[i] = (uint32_t)i;
+    if (boxes.empty()) return;
+    std::vector<float> cen(boxes.size() * 3);
+    for (size_t i = 0; i < boxes.size(); ++i)
+      for (int a = 0; a < 3; ++a) cen[3 * i + a] = 0.5f * (boxes[i].lo[a] + boxes[i].hi[a]);
+    nodes.reserve(boxes.size() * 2);
+    nodes.emplace_back();
+    struct Item { int node; uint32_t first, count; };
+    std::vector<Item> stack{{0, 0u, (uint32_t)boxes.size()}};
+    while (!stack.empty()) {
+      Item it = stack.back();
+      stack.pop_back();
+      BBox nb, cb;
+      nb.reset();
+      cb.reset();
+      for (uint32_t i = it.first; i < it.first + it.count; ++i) {
+        nb.grow(boxes[prim[i]]);
+        cb.grow(&cen[3 * prim[i]]);
+      }
+      nodes[it.node].box = nb;
+      if (it.count <= max_leaf) {
+        nodes[it.node].first = it.first;
+        nodes[it.node].count = it.count;
+        continue;
+      }
+      constexpr int NB = 16;
+      int best_axis = -1, best_split = -1;
+      float best_cost = std::numeric_limits<float>::infinity();
+      for (int a = 0; a < 3; ++a) {
+        float ext = cb.hi[a] - cb.lo[a];
+        if (!(ext > 0.0f)) continue;
+        BBox bb[NB];
+        uint32_t bc[NB] = {0};
+        for (auto& b : bb) b.reset();
+        float scale = (float)NB / ext;
+        for (uint32_t i = it.first; i < it.first + it.count; ++i) {
+          int bi = std::min(NB - 1, (int)((cen[3 * prim[i] + a] - cb.lo[a]) * scale));
+          bb[bi].grow(boxes[prim[i]]);
+          bc[bi]++;
+        }
+        float right_area[NB];
+        uint32_t right_cnt[NB];
+        BBox acc;
+        acc.reset();
+        uint32_t cnt = 0;
+        for (int i = NB - 1; i > 0; --i) {
+          if (bc[i]) acc.grow(bb[i]);
+          cnt += bc[i];
+          right_area[i] = cnt ? acc.half_area() : 0.f;
+          right_cnt[i] = cnt;
+        }
+        acc.reset();
+        cnt = 0;
+        for (int i = 0; i < NB - 1; ++i) {
+          if (bc[i]) acc.grow(bb[i]);
+          cnt += bc[i];
+          if (cnt == 0 || right_cnt[i + 1] == 0) continue;
+          float cost = acc.half_area() * (float)cnt + right_area[i + 1] * (float)right_cnt[i + 1];
+          if (cost < best_cost) { best_cost = cost; best_axis = a; best_split = i; }
+        }
+      }
+      uint32_t mid;
+      if (best_axis < 0) {
+        mid = it.first + it.count / 2;  // all centroids coincide: split by index
+      } else {
+        float ext = cb.hi[best_axis] - cb.lo[best_axis];
+        float scale = (float)NB / ext;
+        auto* b = prim.data() + it.first;
+        auto* e = b + it.count;
+        auto* m = std::partition(b, e, [&](uint32_t p) {
+          int bi = std::min(NB - 1, (int)((cen[3 * p + best_axis] - cb.lo[best_axis]) * scale));
+          return bi <= best_split;
+        });
+        mid = (uint32_t)(m - prim.data());
+        if (mid == it.first || mid == it.first + it.count) mid = it.first + it.count / 2;
+      }
+      int l = (int)nodes.size();
+      nodes.emplace_back();
+      int r = (int)nodes.size();
+      nodes.emplace_back();
+      nodes[it.node].left = l;
+      nodes[it.node].right = r;
+      stack.push_back({r, mid, it.first + it.count - mid});
+      stack.push_back({l, it.first, mid - it.first});
+    }
+  }
+};
+
+inline bool slab(const BBox& b, V3 o, V3 inv, float tmin, float tmax, float& tnear) {
+  float t0 = (b.lo[0] - o.x) * inv.x, t1 = (b.hi[0] - o.x) * inv.x;
+  float lo = std::min(t0, t1), hi = std::max(t0, t1);
+  t0 = (b.lo[1] - o.y) * inv.y; t1 = (b.hi[1] - o.y) * inv.y;
+  lo = std::max(lo, std::min(t0, t1)); hi = std::min(hi, std::max(t0, t1));
+  t0 = (b.lo[2] - o.z) * inv.z; t1 = (b.hi[2] - o.z) * inv.z;
+  lo = std::max(lo, std::min(t0, t1)); hi = std::min(hi, std::max(t0, t1));
+  lo = std::max(lo, tmin);
+  hi = std::min(hi, tmax);
+  tnear = lo;
+  // widen by 2 ulp-ish so a box never rejects a hit its primitive accepts
+  return lo <= hi * 1.0000004f + 1e-30f;
+}
+
+struct Vertex {  // lib.rs:883-890
+  V3 position, normal;
+  V2 uv;
+};
+struct IndexData {  // lib.rs:108-118
+  uint32_t material_index, area_light_index, index_offset, primitive_count;
+};
+struct EmitObject {  // surface_sample.rs:20-33
+  int type;          // 0 triangle, 1 sphere
+  uint32_t index_offset, primitive_count;
+  Affine matrix;
+};
+struct Counters {
+  uint64_t rays_closest = 0, rays_shadow = 0, rays_emitter = 0, paths = 0, bounces = 0, hits = 0,
+           adds = 0, node_visits = 0, prim_tests = 0;
+  void add(const Counters& o) {
+    rays_closest += o.rays_closest; rays_shadow += o.rays_shadow; rays_emitter += o.rays_emitter;
+    paths += o.paths; bounces += o.bounces; hits += o.hits; adds += o.adds;
+    node_visits += o.node_visits; prim_tests += o.prim_tests;
+  }
+};
+
+struct Instance {
+  uint32_t shape;
+  int32_t mesh;
+  Affine o2w, w2o;
+  BBox world_box;
+};
+struct Hit {
+  bool miss = true;
+  float t = 0.f, u = 0.f, v = 0.f;
+  uint32_t instance = 0, primitive = 0;
+};
+struct Payload {  // lib.rs:52-60
+  bool is_miss = true;
+  uint32_t index = 0;
+  float t = 0.f;
+  V3 position = ZERO3, normal = ZERO3;
+  V2 uv = {0.f, 0.f};
+};
+
+struct Scene {
+  uint32_t W = 0, H = 0;
+  rene_uniform uni;
+  M4 c2w, proj_inv, bg_matrix;
+  std::vector<Vertex> vertices;   // global, main.rs:2940-2963
+  std::vector<uint32_t> indices;  // global, rebased
+  std::vector<uint32_t> mesh_index_offset, mesh_prim_count;
+  std::vector<Bvh> blas;          // per mesh, object space
+  std::vector<Instance> instances;
+  std::vector<IndexData> index_data;  // main.rs:3057-3077
+  std::vector<rene_material> materials;
+  std::vector<rene_texture> textures;
+  std::vector<rene_area_light> area_lights;
+  std::vector<rene_light> lights;
+  struct Img { uint32_t w, h; std::vector<float> rgba; };
+  std::vector<Img> images;
+  std::vector<EmitObject> emit_objects;  // main.rs:3143-3158
+  uint32_t emit_object_len = 0, lights_len = 0;
+  Bvh tlas_main, tlas_emit;
+  std::vector<uint32_t> tlas_main_inst, tlas_emit_inst;  // instance ids per TLAS leaf slot
+  std::vector<float> image;  // [3][H][W][4]
+  Counters total;
+  uint64_t frames = 0;
+
+  // ---- traversal (stands in for the Vulkan driver; lib.rs:195-207 etc.) ----
+  bool intersect_instance(uint32_t ii, V3 o, V3 d, float tmin, float& tmax, Hit& hit, bool any,
+                          Counters& c) const {
+    const Instance& in = instances[ii];
+    V3 oo = transform_point(in.w2o, o);
+    V3 od = transform_vector(in.w2o, d);
+    bool found = false;
+    if (in.shape == RENE_SHAPE_SPHERE) {  // sphere_intersection, lib.rs:805-839
+      c.prim_tests++;
+      float a = length_squared(od);
+      float half_b = dot(oo, od);
+      float cc = length_squared(oo) - 1.0f;
+      float disc = half_b * half_b - a * cc;
+      if (disc < 0.0f) return false;
+      float sq = std::sqrt(disc);
+      float root0 = (-half_b - sq) / a;
+      float root1 = (-half_b + sq) / a;
+      float r;
+      if (root0 >= tmin && root0 <= tmax) r = root0;
+      else if (root1 >= tmin && root1 <= tmax) r = root1;
+      else return false;
+      tmax = r;
+      hit.miss = false; hit.t = r; hit.u = 0.f; hit.v = 0.f; hit.instance = ii; hit.primitive = 0;
+      return true;
+    }
+    const Bvh& b = blas[in.mesh];
+    if (b.nodes.empty()) return false;
+    uint32_t ioff = mesh_index_offset[in.mesh];
+    V3 inv = v3(1.0f / od.x, 1.0f / od.y, 1.0f / od.z);
+    int stack[64];
+    int sp = 0;
+    stack[sp++] = 0;
+    float tn;
+    if (!slab(b.nodes[0].box, oo, inv, tmin, tmax, tn)) return false;
+    while (sp) {
+      const Bvh::Node& n = b.nodes[stack[--sp]];
+      if (n.count) {
+        for (uint32_t k = n.first; k < n.first + n.count; ++k) {
+          uint32_t p = b.prim[k];
+          c.prim_tests++;
+          const V3& p0 = vertices[indices[ioff + 3 * p]].position;
+          const V3& p1 = vertices[indices[ioff + 3 * p + 1]].position;
+          const V3& p2 = vertices[indices[ioff + 3 * p + 2]].position;
+          V3 e1 = p1 - p0, e2 = p2 - p0;
+          V3 pv = cross(od, e2);
+          float det = dot(e1, pv);
+          if (det == 0.0f) continue;
+          float inv_det = 1.0f / det;
+          V3 tv = oo - p0;
+          float u = dot(tv, pv) * inv_det;
+          if (u < 0.0f || u > 1.0f) continue;
+          V3 qv = cross(tv, e1);
+          float v = dot(od, qv) * inv_det;
+          if (v < 0.0f || u + v > 1.0f) continue;
+          float t = dot(e2, qv) * inv_det;
+          if (t >= tmin && (hit.miss ? t <= tmax : t < tmax)) {
+            tmax = t;
+            found = true;
+            hit.miss = false; hit.t = t; hit.u = u; hit.v = v; hit.instance = ii; hit.primitive = p;
+            if (any) return true;
+          }
+        }
+        continue;
+      }
+      c.node_visits++;
+      float tl, tr;
+      bool hl = slab(b.nodes[n.left].box, oo, inv, tmin, tmax, tl);
+      bool hr = slab(b.nodes[n.right].box, oo, inv, tmin, tmax, tr);
+      if (hl && hr) {
+        if (tl <= tr) { stack[sp++] = n.right; stack[sp++] = n.left; }
+        else { stack[sp++] = n.left; stack[sp++] = n.right; }
+      } else if (hl) stack[sp++] = n.left;
+      else if (hr) stack[sp++] = n.right;
+    }
+    return found;
+  }
+
+  Hit trace(const Bvh& tlas, const std::vector<uint32_t>& slots, V3 o, V3 d, float tmin, float tmax,
+            bool any, Counters& c) const {
+    Hit hit;
+    if (tlas.nodes.empty()) return hit;
+    V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    int stack[64];
+    int sp = 0;
+    float tn;
+    if (!slab(tlas.nodes[0].box, o, inv, tmin, tmax, tn)) return hit;
+    stack[sp++] = 0;
+    while (sp) {
+      const Bvh::Node& n = tlas.nodes[stack[--sp]];
+      if (n.count) {
+        for (uint32_t k = n.first; k < n.first + n.count; ++k) {
+          uint32_t ii = slots[tlas.prim[k]];
+          float tb;
+          if (!slab(instances[ii].world_box, o, inv, tmin, tmax, tb)) continue;
+          if (intersect_instance(ii, o, d, tmin, tmax, hit, any, c) && any) return hit;
+        }
+        continue;
+      }
+      c.node_visits++;
+      float tl, tr;
+      bool hl = slab(tlas.nodes[n.left].box, o, inv, tmin, tmax, tl);
+      bool hr = slab(tlas.nodes[n.right].box, o, inv, tmin, tmax, tr);
+      if (hl && hr) {
+        if (tl <= tr) { stack[sp++] = n.right; stack[sp++] = n.left; }
+        else { stack[sp++] = n.left; stack[sp++] = n.right; }
+      } else if (hl) stack[sp++] = n.left;
+      else if (hr) stack[sp++] = n.right;
+    }
+    return hit;
+  }
+
+  // ---- hit shaders ----
+  void tri_verts(uint32_t instance, uint32_t prim, Vertex& v0, Vertex& v1, Vertex& v2) const {
+    uint32_t off = index_data[instance].index_offset;  // lib.rs:906-924
+    v0 = vertices[indices[off + 3 * prim]];
+    v1 = vertices[indices[off + 3 * prim + 1]];
+    v2 = vertices[indices[off + 3 * prim + 2]];
+  }
+  Payload closest_hit(const Hit& h, V3 o, V3 d) const {
+    Payload out;
+    if (h.miss) return out;
+    const Instance& in = instances[h.instance];
+    out.is_miss = false;
+    out.t = h.t;
+    out.index = h.instance;
+    if (in.shape == RENE_SHAPE_SPHERE) {  // sphere_closest_hit, lib.rs:852-881
+      V3 oo = transform_point(in.w2o, o);
+      V3 od = transform_vector(in.w2o, d);
+      V3 hit_pos = o + h.t * d;
+      V3 ohp = oo + h.t * od;
+      float phi = std::atan2(ohp.y, ohp.x);
+      if (phi < 0.0f) phi = phi + 2.0f * PI;
+      float theta = std::acos(ohp.z);
+      float u = phi * FRAC_1_PI * 0.5f;
+      float v = (theta - PI) * -FRAC_1_PI;
+      out.position = hit_pos;
+      out.normal = v3(dot(in.w2o.x, ohp), dot(in.w2o.y, ohp), dot(in.w2o.z, ohp));
+      out.uv = V2{u, v};
+      return out;
+    }
+    Vertex v0, v1, v2;  // triangle_closest_hit, lib.rs:892-952
+    tri_verts(h.instance, h.primitive, v0, v1, v2);
+    V3 bary = v3(1.0f - h.u - h.v, h.u, h.v);
+    V3 pos = v0.position * bary.x + v1.position * bary.y + v2.position * bary.z;
+    V3 nrm;
+    if (v0.normal == ZERO3 && v1.normal == ZERO3 && v2.normal == ZERO3)
+      nrm = cross(v1.position - v0.position, v2.position - v0.position);
+    else
+      nrm = v0.normal * bary.x + v1.normal * bary.y + v2.normal * bary.z;
+    V2 uv = {v0.uv.x * bary.x + v1.uv.x * bary.y + v2.uv.x * bary.z,
+             v0.uv.y * bary.x + v1.uv.y * bary.y + v2.uv.y * bary.z};
+    out.position = pos.x * in.o2w.x + pos.y * in.o2w.y + pos.z * in.o2w.z + in.o2w.w;
+    out.normal = normalize(v3(dot(in.w2o.x, nrm), dot(in.w2o.y, nrm), dot(in.w2o.z, nrm)));
+    out.uv = uv;
+    return out;
+  }
+  float closest_hit_pdf(const Hit& h, V3 o, V3 d) const {
+    if (h.miss) return 0.0f;  // main_miss_pdf, lib.rs:959-962
+    const Instance& in = instances[h.instance];
+    if (in.shape == RENE_SHAPE_SPHERE) {  // sphere_closest_hit_pdf, lib.rs:1047-1066 (Q4)
+      float radius = (std::fabs(in.o2w.x.x) + std::fabs(in.o2w.y.y) + std::fabs(in.o2w.z.z)) / 3.0f;
+      V3 center = in.o2w.w;
+      float cos_theta_max =
+          std::sqrt(std::max(1.0f - radius * radius / length_squared(center - o), 0.0f));
+      float solid_angle = 2.0f * PI * (1.0f - cos_theta_max);
+      return 1.0f / solid_angle;
+    }
+    Vertex v0, v1, v2;  // triangle_closest_hit_pdf, lib.rs:964-1045
+    tri_verts(h.instance, h.primitive, v0, v1, v2);
+    V3 bary = v3(1.0f - h.u - h.v, h.u, h.v);
+    V3 pos = v0.position * bary.x + v1.position * bary.y + v2.position * bary.z;
+    V3 nrm = cross(v1.position - v0.position, v2.position - v0.position);
+    V3 p0 = transform_point(in.o2w, v0.position);
+    V3 p1 = transform_point(in.o2w, v1.position);
+    V3 p2 = transform_point(in.o2w, v2.position);
+    V3 hit_pos = transform_point(in.o2w, pos);
+    V3 normal = normalize(v3(dot(in.w2o.x, nrm), dot(in.w2o.y, nrm), dot(in.w2o.z, nrm)));
+    V3 ab = p1 - p0, ac = p2 - p0;
+    float area = 0.5f * length(cross(ab, ac));
+    float distance_squared = length_squared(o - hit_pos);
+    float cosine = std::fabs(dot(normalize(d), normal));
+    return distance_squared / (cosine * area) / (float)index_data[h.instance].primitive_count;
+  }
+
+  // ---- texture.rs ----
+  V3 image_sample(uint32_t img, float u, float v) const {
+    // SampledImage::sample_by_lod with LINEAR filter, REPEAT addressing (main.rs:2390-2397)
+    const Img& im = images[img];
+    float x = u * (float)im.w - 0.5f, y = v * (float)im.h - 0.5f;
+    float fx = std::floor(x), fy = std::floor(y);
+    float ax = x - fx, ay = y - fy;
+    auto wrap = [](int i, int n) { int m = i % n; return m < 0 ? m + n : m; };
+    int x0 = wrap((int)fx, (int)im.w), x1 = wrap((int)fx + 1, (int)im.w);
+    int y0 = wrap((int)fy, (int)im.h), y1 = wrap((int)fy + 1, (int)im.h);
+    auto px = [&](int xx, int yy) {
+      const float* p = &im.rgba[4 * ((size_t)yy * im.w + xx)];
+      return v3(p[0], p[1], p[2]);
+    };
+    V3 top = px(x0, y0) * (1.0f - ax) + px(x1, y0) * ax;
+    V3 bot = px(x0, y1) * (1.0f - ax) + px(x1, y1) * ax;
+    return top * (1.0f - ay) + bot * ay;
+  }
+  V3 tex_color_non_recursive(uint32_t index, V2 uv) const {  // texture.rs:175-190
+    const rene_texture& t = textures[index];
+    switch (t.type) {
+      case RENE_TEXTURE_SOLID: return v3(t.v0[0], t.v0[1], t.v0[2]);
+      case RENE_TEXTURE_IMAGEMAP: return image_sample(t.u0[0], uv.x, 1.0f - uv.y);  // texture.rs:121-127
+      default: return ONE3;
+    }
+  }
+  V3 tex_color(uint32_t index, V2 uv) const {  // texture.rs:192-211
+    const rene_texture& t = textures[index];
+    switch (t.type) {
+      case RENE_TEXTURE_SOLID: return v3(t.v0[0], t.v0[1], t.v0[2]);
+      case RENE_TEXTURE_IMAGEMAP: return image_sample(t.u0[0], uv.x, 1.0f - uv.y);
+      case RENE_TEXTURE_CHECKERBOARD: {  // texture.rs:97-118
+        float x = uv.x * t.v0[0], y = uv.y * t.v0[1];
+        uint32_t idx = ((f32_to_u32(x) % 2 == 0) == (f32_to_u32(y) % 2 == 0)) ? t.u0[0] : t.u0[1];
+        return tex_color_non_recursive(idx, V2{fract(x), fract(y)});
+      }
+      default:  // Scale
+        return tex_color_non_recursive(t.u0[0], uv) * tex_color_non_recursive(t.u0[1], uv);
+    }
+  }
+
+  // ---- material.rs ----
+  V3 albedo(const rene_material& m, V2 uv) const {  // material.rs:720-737
+    switch (m.type) {
+      case RENE_MATERIAL_MATTE: return tex_color(m.u0[0], uv);      // 118-125
+      case RENE_MATERIAL_SUBSTRATE: return tex_color(m.u0[0], uv);  // 218-225
+      case RENE_MATERIAL_METAL: return tex_color(m.u0[1], uv);      // 309-316 (k)
+      case RENE_MATERIAL_MIRROR: return tex_color(m.u0[0], uv);     // 375-382
+      case RENE_MATERIAL_UBER: return tex_color(m.u0[0], uv);       // 632-639
+      case RENE_MATERIAL_PLASTIC: return tex_color(m.u0[0], uv);    // 709-716
+      default: return ZERO3;                                        // None, Glass 333-340
+    }
+  }
+  void compute_bsdf(const rene_material& m, Bsdf& bsdf, V2 uv) const {  // material.rs:739-769
+    switch (m.type) {
+      case RENE_MATERIAL_MATTE: {  // 127-135
+        Bxdf& b = bsdf.add_mut();
+        b.type = BX_LAMBERT;
+        b.a = tex_color(m.u0[0], uv);
+        break;
+      }
+      case RENE_MATERIAL_GLASS: {  // 342-350
+        Bxdf& b = bsdf.add_mut();
+        b.type = BX_FRESNEL_SPECULAR;
+        b.a.x = m.v0[0];
+        break;
+      }
+      case RENE_MATERIAL_SUBSTRATE: {  // 188-216
+        V3 d = tex_color(m.u0[0], uv);
+        V3 s = tex_color(m.u0[1], uv);
+        float ru = tex_color(m.u0[2], uv).x, rv = tex_color(m.u0[3], uv).x;
+        if (m.u1[0] != 0) { ru = roughness_to_alpha(ru); rv = roughness_to_alpha(rv); }
+        Bxdf& b = bsdf.add_mut();
+        b.type = BX_FRESNEL_BLEND;
+        b.a = d;
+        b.b = s;
+        b.dist.alpha_x = ru;
+        b.dist.alpha_y = rv;
+        break;
+      }
+      case RENE_MATERIAL_METAL: {  // 279-307
+        float ru = tex_color(m.u0[2], uv).x, rv = tex_color(m.u0[3], uv).x;
+        if (m.u1[0] != 0) { ru = roughness_to_alpha(ru); rv = roughness_to_alpha(rv); }
+        Bxdf& b = bsdf.add_mut();
+        b.type = BX_MICROFACET_REFLECTION;
+        b.a = ONE3;
+        b.dist.alpha_x = ru;
+        b.dist.alpha_y = rv;
+        b.fresnel = Fresnel::conductor(ONE3, tex_color(m.u0[0], uv), tex_color(m.u0[1], uv));
+        break;
+      }
+      case RENE_MATERIAL_MIRROR: {  // 363-373
+        Bxdf& b = bsdf.add_mut();
+        b.type = BX_SPECULAR_REFLECTION;
+        b.a = tex_color(m.u0[0], uv);
+        b.fresnel = Fresnel::nop();
+        break;
+      }
+      case RENE_MATERIAL_UBER: {  // 579-630
+        float e = m.v0[0];
+        V3 op = tex_color(m.u1[0], uv);
+        V3 t = ONE3 - op;
+        if (t != ZERO3) {
+          Bxdf& b = bsdf.add_mut();
+          b.type = BX_SPECULAR_TRANSMISSION; b.a = t; b.b = v3(1.0f, 1.0f, 0.f);
+        }
+        V3 kd = tex_color(m.u0[0], uv);
+        if (kd != ZERO3) {
+          Bxdf& b = bsdf.add_mut();
+          b.type = BX_LAMBERT; b.a = kd;
+        }
+        V3 ks = tex_color(m.u0[1], uv);
+        if (ks != ZERO3) {
+          float ru = tex_color(m.u1[2], uv).x, rv = tex_color(m.u1[3], uv).x;
+          if (m.u1[1] != 0) { ru = roughness_to_alpha(ru); rv = roughness_to_alpha(rv); }
+          Bxdf& b = bsdf.add_mut();
+          b.type = BX_MICROFACET_REFLECTION; b.a = ks;
+          b.dist.alpha_x = ru; b.dist.alpha_y = rv;
+          b.fresnel = Fresnel::dielectric(1.0f, e);
+        }
+        V3 kr = op * tex_color(m.u0[2], uv);
+        if (kr != ZERO3) {
+          Bxdf& b = bsdf.add_mut();
+          b.type = BX_SPECULAR_REFLECTION; b.a = kr; b.fresnel = Fresnel::dielectric(1.0f, e);
+        }
+        V3 kt = op * tex_color(m.u0[3], uv);
+        if (kt != ZERO3) {
+          Bxdf& b = bsdf.add_mut();
+          b.type = BX_SPECULAR_TRANSMISSION; b.a = kt; b.b = v3(1.0f, e, 0.f);
+        }
+        break;
+      }
+      case RENE_MATERIAL_PLASTIC: {  // 680-707
+        V3 kd = tex_color(m.u0[0], uv);
+        if (kd != ZERO3) {
+          Bxdf& b = bsdf.add_mut();
+          b.type = BX_LAMBERT; b.a = kd;
+        }
+        V3 ks = tex_color(m.u0[1], uv);
+        if (ks != ZERO3) {
+          float rough = tex_color(m.u0[3], uv).x;
+          if (m.u1[2] != 0) rough = roughness_to_alpha(rough);  // Q8: u1.z is never set (674-676)
+          Bxdf& b = bsdf.add_mut();
+          b.type = BX_MICROFACET_REFLECTION; b.a = ks;
+          b.dist.alpha_x = rough; b.dist.alpha_y = rough;
+          b.fresnel = Fresnel::dielectric(1.5f, 1.0f);
+        }
+        break;
+      }
+      default: break;  // None
+    }
+  }
+
+  // ---- surface_sample.rs:69-117 ----
+  V3 emit_sample(const EmitObject& e, PCG32si& rng) const {
+    if (e.type == 0) {  // Triangle::sample, 74-105 (Q6: uniform by index)
+      uint32_t p = rng.next_u32() % e.primitive_count;
+      const Vertex& v0 = vertices[indices[e.index_offset + 3 * p]];
+      const Vertex& v1 = vertices[indices[e.index_offset + 3 * p + 1]];
+      const Vertex& v2 = vertices[indices[e.index_offset + 3 * p + 2]];
+      float r = rng.next_f32();
+      float s = rng.next_f32();
+      if (r + s > 1.0f) { r = 1.0f - r; s = 1.0f - s; }
+      V3 pos = v0.position * (1.0f - r - s) + v1.position * r + v2.position * s;
+      return transform_point(e.matrix, pos);
+    }
+    V3 v = normalize(random_in_unit_sphere(rng));  // Sphere::sample, 113-116
+    return transform_point(e.matrix, v);
+  }
+
+  // ---- camera.rs:77-90 ----
+  void camera_ray(float s, float t, V3& origin, V3& dir) const {
+    origin = m4_transform_point(c2w, v3(0.f, 0.f, 0.f));
+    V3 target = m4_transform_point(proj_inv, v3(s * 2.0f - 1.0f, t * 2.0f - 1.0f, 1.0f));
+    target = m4_transform_point(c2w, target);
+    dir = normalize(target - origin);
+  }
+
+  // ---- lib.rs:120-139 main_miss ----
+  V3 miss_color(V3 dir) const {
+    V2 uv = sphere_uv(normalize(m4_transform_vector(bg_matrix, dir)));
+    return v3(uni.background_color[0], uni.background_color[1], uni.background_color[2]) *
+           tex_color(uni.background_texture, uv);
+  }
+
+  // ---- lib.rs:141-357 main_ray_generation_path; one (pixel, frame) ----
+  void raygen(uint32_t x, uint32_t y, uint32_t seed, Counters& c) {
+    auto add_image = [&](uint32_t layer, V3 v) {  // lib.rs:165-172
+      float* p = &image[(((size_t)layer * H + (H - 1 - y)) * W + x) * 4];
+      p[0] = p[0] + v.x; p[1] = p[1] + v.y; p[2] = p[2] + v.z; p[3] = p[3] + 0.0f;
+      c.adds++;
+    };
+    c.paths++;
+    uint32_t rand_seed = (y * W + x) ^ seed;  // lib.rs:174
+    PCG32si rng(rand_seed);
+    PCG32si frame_wide_rng(seed);
+    float u = ((float)x + rng.next_f32()) / (float)(W - 1);  // Q2, lib.rs:178-179
+    float v = ((float)y + rng.next_f32()) / (float)(H - 1);
+    const float tmin = 0.001f, tmax = 100000.0f;
+    Bsdf bsdf;
+    bsdf.onb = Onb::from_w(v3(0.f, 0.f, 1.f));
+    V3 color = ONE3;
+    V3 ro, rd;
+    camera_ray(u, v, ro, rd);
+    int i = 0;
+    while (i < 50) {  // Q7
+      c.rays_closest++;
+      Hit h = trace(tlas_main, tlas_main_inst, ro, rd, tmin, tmax, false, c);
+      if (h.miss) {
+        add_image(0, color * miss_color(rd));  // lib.rs:209-211
+        break;
+      } else {
+        Payload payload = closest_hit(h, ro, rd);
+        c.hits++;
+        c.bounces++;
+        V3 wo = -normalize(rd);
+        V3 normal = normalize(payload.normal);
+        V3 position = payload.position;
+        V2 uv = payload.uv;
+        const IndexData& index = index_data[payload.index];
+        const rene_material& material = materials[index.material_index];
+        const rene_area_light& area_light = area_lights[index.area_light_index];
+        bsdf.clear(normal, Onb::from_w(normal));
+        compute_bsdf(material, bsdf, uv);
+        if (area_light.type != RENE_AREA_LIGHT_NULL) {  // lib.rs:225-227, area_light.rs:66-74 (A15)
+          V3 e = dot(wo, normal) > 0.0f ? v3(area_light.v0[0], area_light.v0[1], area_light.v0[2]) : ZERO3;
+          add_image(0, color * e);
+        }
+        if (i == 0) {  // lib.rs:229-232
+          add_image(1, normal);
+          add_image(2, albedo(material, uv));
+        }
+        for (uint32_t l = 0; l < lights_len; ++l) {  // lib.rs:234-272, light.rs:52-60
+          const rene_light& lt = lights[l];
+          V3 target = position + v3(lt.v0[0], lt.v0[1], lt.v0[2]);
+          float t_max = 1e5f;
+          V3 wi = normalize(target - position);
+          c.rays_shadow++;
+          Hit sh = trace(tlas_main, tlas_main_inst, position, wi, tmin, t_max, true, c);
+          if (sh.miss) {
+            V3 f = bsdf.f(wo, wi);
+            add_image(0, color * f * std::fabs(dot(wi, normal)) * v3(lt.v1[0], lt.v1[1], lt.v1[2]));
+          }
+        }
+        if (emit_object_len > 0 && bsdf.contains(K_DIFFUSE)) {  // lib.rs:274-324
+          V3 wi, f;
+          float pdf;
+          if (frame_wide_rng.next_f32() > 0.5f) {  // Q3
+            const EmitObject& eo = emit_objects[frame_wide_rng.next_u32() % emit_object_len];
+            wi = normalize(emit_sample(eo, frame_wide_rng) - position);
+            pdf = bsdf.pdf(wi, normal);  // Q1: (wi, normal), lib.rs:287
+            f = bsdf.f(wo, wi);
+          } else {
+            SampledF s = bsdf.sample_f(wo, rng);
+            wi = s.wi; pdf = s.pdf; f = s.f;
+          }
+          ro = position;
+          rd = wi;
+          c.rays_emitter++;
+          Hit eh = trace(tlas_emit, tlas_emit_inst, ro, rd, tmin, tmax, false, c);  // Q5
+          float pdf_l = closest_hit_pdf(eh, ro, rd);
+          color *= f * std::fabs(dot(normal, wi));
+          pdf = 0.5f * pdf + 0.5f * pdf_l / (float)emit_object_len;
+          if (pdf < 1e-5f) break;
+          color /= pdf;
+        } else {  // lib.rs:325-337
+          SampledF s = bsdf.sample_f(wo, rng);
+          if (s.pdf < 1e-5f) break;
+          color *= s.f * std::fabs(dot(normal, s.wi)) / s.pdf;
+          ro = position;
+          rd = s.wi;
+        }
+      }
+      if (color == ZERO3) break;  // lib.rs:340-342
+      if (i > 12) {               // lib.rs:345-354
+        float rr_coin = frame_wide_rng.next_f32();
+        float continue_p = max_element(color);
+        if (rr_coin > continue_p) break;
+        color /= continue_p;
+      }
+      i += 1;
+    }
+  }
+};
+
+void mesh_boxes(const Scene& s, uint32_t mesh, std::vector<BBox>& out) {
+  uint32_t off = s.mesh_index_offset[mesh], n = s.mesh_prim_count[mesh];
+  out.resize(n);
+  for (uint32_t p = 0; p < n; ++p) {
+    out[p].reset();
+    for (int k = 0; k < 3; ++k) out[p].grow(&s.vertices[s.indices[off + 3 * p + k]].position.x);
+  }
+}
+
+thread_local std::string g_err;
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+struct oracle_ctx {
+  Scene s;
+};
+
+const char* oracle_last_error() { return g_err.c_str(); }
+
+int oracle_create(const rene_scene_desc* d, oracle_ctx** out) {
+  if (!d || !out || d->struct_size != sizeof(rene_scene_desc)) { g_err = "bad scene desc"; return -1; }
+  if (d->integrator != RENE_INTEGRATOR_PATH) { g_err = "volpath not restated"; return -4; }
+  auto ctx = std::make_unique<oracle_ctx>();
+  Scene& s = ctx->s;
+  s.W = d->xresolution; s.H = d->yresolution;
+  s.uni = d->uniform;
+  std::memcpy(s.c2w.m, d->uniform.camera_to_world, 64);
+  std::memcpy(s.proj_inv.m, d->uniform.projection_inv, 64);
+  std::memcpy(s.bg_matrix.m, d->uniform.background_matrix, 64);
+  // global vertex/index arrays with index rebasing, main.rs:2943-2963
+  for (uint32_t m = 0; m < d->n_meshes; ++m) {
+    const rene_mesh& me = d->meshes[m];
+    uint32_t voff = (uint32_t)s.vertices.size();
+    s.mesh_index_offset.push_back((uint32_t)s.indices.size());
+    s.mesh_prim_count.push_back(me.n_indices / 3);
+    for (uint32_t i = 0; i < me.n_vertices; ++i) {
+      const rene_vertex& v = me.vertices[i];
+      s.vertices.push_back(Vertex{{v.position[0], v.position[1], v.position[2]},
+                                  {v.normal[0], v.normal[1], v.normal[2]}, {v.uv[0], v.uv[1]}});
+    }
+    for (uint32_t i = 0; i < me.n_indices; ++i) {
+      if (me.indices[i] >= me.n_vertices) { g_err = "index out of range"; return -2; }
+      s.indices.push_back(me.indices[i] + voff);
+    }
+  }
+  s.materials.assign(d->materials, d->materials + d->n_materials);
+  s.textures.assign(d->textures, d->textures + d->n_textures);
+  s.area_lights.assign(d->area_lights, d->area_lights + d->n_area_lights);
+  s.lights.assign(d->lights, d->lights + d->n_lights);
+  s.lights_len = d->n_lights;  // scene.rs:166
+  for (uint32_t i = 0; i < d->n_images; ++i) {
+    Scene::Img im{d->images[i].width, d->images[i].height, {}};
+    im.rgba.assign(d->images[i].rgba, d->images[i].rgba + (size_t)4 * im.w * im.h);
+    s.images.push_back(std::move(im));
+  }
+  s.blas.resize(d->n_meshes);
+  for (uint32_t m = 0; m < d->n_meshes; ++m) {
+    std::vector<BBox> boxes;
+    mesh_boxes(s, m, boxes);
+    s.blas[m].build(boxes, 4);
+  }
+  std::vector<BBox> main_boxes, emit_boxes;
+  for (uint32_t i = 0; i < d->n_instances; ++i) {
+    const rene_instance& ri = d->instances[i];
+    Instance in;
+    in.shape = ri.shape;
+    in.mesh = ri.mesh_index;
+    in.o2w = affine_from12(ri.matrix);
+    in.w2o = affine_inverse(in.o2w);
+    in.world_box.reset();
+    BBox ob;
+    if (ri.shape == RENE_SHAPE_SPHERE) {  // unit AABB BLAS, main.rs:2444-2451
+      ob.lo[0] = ob.lo[1] = ob.lo[2] = -1.0f;
+      ob.hi[0] = ob.hi[1] = ob.hi[2] = 1.0f;
+    } else {
+      if (ri.mesh_index < 0 || (uint32_t)ri.mesh_index >= d->n_meshes) { g_err = "bad mesh index"; return -2; }
+      if (s.blas[ri.mesh_index].nodes.empty()) { ob.lo[0] = ob.lo[1] = ob.lo[2] = 0; ob.hi[0] = ob.hi[1] = ob.hi[2] = 0; }
+      else ob = s.blas[ri.mesh_index].nodes[0].box;
+    }
+    for (int c = 0; c < 8; ++c) {
+      V3 p = v3(c & 1 ? ob.hi[0] : ob.lo[0], c & 2 ? ob.hi[1] : ob.lo[1], c & 4 ? ob.hi[2] : ob.lo[2]);
+      V3 w = transform_point(in.o2w, p);
+      in.world_box.grow(&w.x);
+    }
+    // pad so that fp error in the world-space transform can never clip a true hit
+    for (int a = 0; a < 3; ++a) {
+      float pad = 1e-5f * std::max(std::fabs(in.world_box.lo[a]), std::fabs(in.world_box.hi[a])) + 1e-6f;
+      in.world_box.lo[a] -= pad;
+      in.world_box.hi[a] += pad;
+    }
+    s.instances.push_back(in);
+    IndexData id;  // main.rs:3064-3077
+    id.material_index = ri.material_index;
+    id.area_light_index = ri.area_light_index;
+    id.index_offset = ri.shape == RENE_SHAPE_TRIANGLE ? s.mesh_index_offset[ri.mesh_index] : 0;
+    id.primitive_count = ri.shape == RENE_SHAPE_TRIANGLE ? s.mesh_prim_count[ri.mesh_index] : 1;
+    s.index_data.push_back(id);
+    if (ri.material_index >= d->n_materials || ri.area_light_index >= d->n_area_lights) { g_err = "bad table index"; return -2; }
+    main_boxes.push_back(in.world_box);
+    s.tlas_main_inst.push_back(i);
+    if (s.area_lights[ri.area_light_index].type != RENE_AREA_LIGHT_NULL) {  // main.rs:3109-3116, 3143-3158
+      emit_boxes.push_back(in.world_box);
+      s.tlas_emit_inst.push_back(i);
+      EmitObject e;
+      e.type = ri.shape == RENE_SHAPE_SPHERE ? 1 : 0;
+      e.index_offset = id.index_offset;
+      e.primitive_count = id.primitive_count;
+      e.matrix = in.o2w;
+      s.emit_objects.push_back(e);
+    }
+  }
+  s.emit_object_len = (uint32_t)s.emit_objects.size();  // main.rs:3279
+  s.tlas_main.build(main_boxes, 2);
+  s.tlas_emit.build(emit_boxes, 2);
+  s.image.assign((size_t)3 * s.W * s.H * 4, 0.0f);
+  *out = ctx.release();
+  return 0;
+}
+
+void oracle_destroy(oracle_ctx* c) { delete c; }
+
+void oracle_reset(oracle_ctx* c) {
+  std::fill(c->s.image.begin(), c->s.image.end(), 0.0f);
+  c->s.total = Counters();
+  c->s.frames = 0;
+}
+
+// frames [first, first+n) with the build-defined seed schedule; pixels sharded like the
+// product (tile t -> rank t % count, or frame k -> rank k % count)
+int oracle_render(oracle_ctx* c, uint32_t master_seed, uint32_t first_frame, uint32_t n_frames,
+                  int n_threads, uint32_t shard_mode, uint32_t shard_rank, uint32_t shard_count) {
+  Scene& s = c->s;
+  if (shard_count == 0) shard_count = 1;
+  std::vector<uint32_t> seeds(n_frames);
+  {
+    PCG32si m(master_seed);
+    for (uint32_t k = 0; k < first_frame; ++k) m.next_u32();
+    for (uint32_t k = 0; k < n_frames; ++k) seeds[k] = m.next_u32();
+  }
+  if (n_threads <= 0) n_threads = (int)std::max(1u, std::thread::hardware_concurrency());
+  std::atomic<uint32_t> next_row{0};
+  std::vector<Counters> cs(n_threads);
+  const uint32_t tiles_x = (s.W + RENE_TILE_SIZE - 1) / RENE_TILE_SIZE;
+  auto work = [&](int tid) {
+    Counters& cc = cs[tid];
+    for (;;) {
+      uint32_t y = next_row.fetch_add(1);
+      if (y >= s.H) break;
+      for (uint32_t x = 0; x < s.W; ++x) {
+        if (shard_mode == RENE_SHARD_TILES && shard_count > 1) {
+          // tiles are laid out over the *image* rows (top row first): image row = H-1-y
+          uint32_t tile = ((s.H - 1 - y) / RENE_TILE_SIZE) * tiles_x + x / RENE_TILE_SIZE;
+          if (tile % shard_count != shard_rank) continue;
+        }
+        for (uint32_t k = 0; k < n_frames; ++k) {
+          if (shard_mode == RENE_SHARD_FRAMES && shard_count > 1 &&
+              (first_frame + k) % shard_count != shard_rank)
+            continue;
+          s.raygen(x, y, seeds[k], cc);
+        }
+      }
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < n_threads; ++t) th.emplace_back(work, t);
+  work(0);
+  for (auto& t : th) t.join();
+  for (auto& cc : cs) s.total.add(cc);
+  s.frames += n_frames;
+  return 0;
+}
+
+int oracle_download(oracle_ctx* c, int layer, int channels, float* dst, size_t dst_floats) {
+  Scene& s = c->s;
+  size_t n = (size_t)s.W * s.H;
+  if (layer < 0 || layer > 2 || (channels != 3 && channels != 4) || dst_floats < n * channels) return -1;
+  const float* src = &s.image[(size_t)layer * n * 4];
+  for (size_t i = 0; i < n; ++i)
+    for (int ch = 0; ch < channels; ++ch) dst[i * channels + ch] = src[i * 4 + ch];
+  return 0;
+}
+
+int oracle_get_stats(oracle_ctx* c, rene_stats* out) {
+  std::memset(out, 0, sizeof(*out));
+  const Counters& t = c->s.total;
+  out->rays_closest = t.rays_closest; out->rays_shadow = t.rays_shadow; out->rays_emitter = t.rays_emitter;
+  out->paths = t.paths; out->bounces = t.bounces; out->hits = t.hits; out->adds = t.adds;
+  out->node_visits = t.node_visits; out->prim_tests = t.prim_tests; out->frames = c->s.frames;
+  return 0;
+}
+
+int oracle_trace(oracle_ctx* c, int which, size_t n, const float* o, const float* d, float tmin,
+                 float tmax, rene_hit* out) {
+  Scene& s = c->s;
+  Counters cc;
+  for (size_t i = 0; i < n; ++i) {
+    Hit h = s.trace(which ? s.tlas_emit : s.tlas_main, which ? s.tlas_emit_inst : s.tlas_main_inst,
+                    v3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), v3(d[3 * i], d[3 * i + 1], d[3 * i + 2]),
+                    tmin, tmax, false, cc);
+    out[i].t = h.miss ? -1.0f : h.t;
+    out[i].u = h.u; out[i].v = h.v; out[i].instance = h.instance; out[i].primitive = h.primitive;
+  }
+  return 0;
+}
+
+// brute force over every primitive, no BVH at all: pins the oracle's own traversal
+int oracle_trace_bruteforce(oracle_ctx* c, int which, size_t n, const float* o, const float* d,
+                            float tmin, float tmax, rene_hit* out) {
+  Scene& s = c->s;
+  const auto& slots = which ? s.tlas_emit_inst : s.tlas_main_inst;
+  for (size_t i = 0; i < n; ++i) {
+    V3 ro = v3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), rd = v3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+    Hit best;
+    float tm = tmax;
+    for (uint32_t ii : slots) {
+      const Instance& in = s.instances[ii];
+      V3 oo = transform_point(in.w2o, ro), od = transform_vector(in.w2o, rd);
+      if (in.shape == RENE_SHAPE_SPHERE) {
+        Counters cc;
+        s.intersect_instance(ii, ro, rd, tmin, tm, best, false, cc);
+        continue;
+      }
+      uint32_t ioff = s.mesh_index_offset[in.mesh];
+      for (uint32_t p = 0; p < s.mesh_prim_count[in.mesh]; ++p) {
+        V3 p0 = s.vertices[s.indices[ioff + 3 * p]].position;
+        V3 e1 = s.vertices[s.indices[ioff + 3 * p + 1]].position - p0;
+        V3 e2 = s.vertices[s.indices[ioff + 3 * p + 2]].position - p0;
+        V3 pv = cross(od, e2);
+        float det = dot(e1, pv);
+        if (det == 0.0f) continue;
+        float inv_det = 1.0f / det;
+        V3 tv = oo - p0;
+        float u = dot(tv, pv) * inv_det;
+        if (u < 0.0f || u > 1.0f) continue;
+        V3 qv = cross(tv, e1);
+        float v = dot(od, qv) * inv_det;
+        if (v < 0.0f || u + v > 1.0f) continue;
+        float t = dot(e2, qv) * inv_det;
+        if (t >= tmin && t <= tm && (t < tm || best.miss)) {
+          tm = t;
+          best.miss = false; best.t = t; best.u = u; best.v = v; best.instance = ii; best.primitive = p;
+        }
+      }
+    }
+    out[i].t = best.miss ? -1.0f : best.t;
+    out[i].u = best.u; out[i].v = best.v; out[i].instance = best.instance; out[i].primitive = best.primitive;
+  }
+  return 0;
+}
+
+// ---- scalar hooks for known-answer / per-function tests ----------------------------------------
+void oracle_pcg_state_after_new(uint32_t seed, uint32_t* state) { *state = PCG32si(seed).state; }
+void oracle_pcg_u32(uint32_t seed, uint32_t n, uint32_t* out) {
+  PCG32si r(seed);
+  for (uint32_t i = 0; i < n; ++i) out[i] = r.next_u32();
+}
+void oracle_pcg_f32(uint32_t seed, uint32_t n, float* out) {
+  PCG32si r(seed);
+  for (uint32_t i = 0; i < n; ++i) out[i] = r.next_f32();
+}
+void oracle_camera_ray(oracle_ctx* c, float s, float t, float* o3, float* d3) {
+  V3 o, d;
+  c->s.camera_ray(s, t, o, d);
+  o3[0] = o.x; o3[1] = o.y; o3[2] = o.z; d3[0] = d.x; d3[1] = d.y; d3[2] = d.z;
+}
+// evaluate the BSDF of `material_index` at shading normal n / uv: f(wo,wi), pdf(wo,wi) and one
+// sample_f(wo) drawn from PCG32si::new(seed).  out = f[3], pdf, s.wi[3], s.f[3], s.pdf, len
+void oracle_bsdf_eval(oracle_ctx* c, uint32_t material_index, const float* n3, const float* uv2,
+                      const float* wo3, const float* wi3, uint32_t seed, float* out12) {
+  Scene& s = c->s;
+  V3 n = normalize(v3(n3[0], n3[1], n3[2]));
+  Bsdf b;
+  b.clear(n, Onb::from_w(n));
+  s.compute_bsdf(s.materials[material_index], b, V2{uv2[0], uv2[1]});
+  V3 wo = v3(wo3[0], wo3[1], wo3[2]), wi = v3(wi3[0], wi3[1], wi3[2]);
+  V3 f = b.f(wo, wi);
+  float p = b.len ? b.pdf(wo, wi) : 0.0f;
+  PCG32si rng(seed);
+  SampledF sf = b.sample_f(wo, rng);
+  out12[0] = f.x; out12[1] = f.y; out12[2] = f.z; out12[3] = p;
+  out12[4] = sf.wi.x; out12[5] = sf.wi.y; out12[6] = sf.wi.z;
+  out12[7] = sf.f.x; out12[8] = sf.f.y; out12[9] = sf.f.z; out12[10] = sf.pdf; out12[11] = (float)b.len;
+}
+void oracle_fr_dielectric(float c, float ei, float et, float* out) { *out = fr_dielectric(c, ei, et); }
+void oracle_fr_conductor(float c, const float* ei, const float* et, const float* k, float* out3) {
+  V3 r = fr_conductor(c, v3(ei[0], ei[1], ei[2]), v3(et[0], et[1], et[2]), v3(k[0], k[1], k[2]));
+  out3[0] = r.x; out3[1] = r.y; out3[2] = r.z;
+}
+void oracle_tr_d_lambda(float ax, float ay, const float* w3, float* out2) {
+  TrowbridgeReitz t;
+  t.alpha_x = ax; t.alpha_y = ay;
+  out2[0] = t.d(v3(w3[0], w3[1], w3[2]));
+  out2[1] = t.lambda(v3(w3[0], w3[1], w3[2]));
+}
+void oracle_roughness_to_alpha(float r, float* out) { *out = roughness_to_alpha(r); }
+void oracle_tex_color(oracle_ctx* c, uint32_t tex, float u, float v, float* out3) {
+  V3 r = c->s.tex_color(tex, V2{u, v});
+  out3[0] = r.x; out3[1] = r.y; out3[2] = r.z;
+}
+void oracle_scene_info(oracle_ctx* c, uint32_t* out4) {
+  out4[0] = c->s.emit_object_len; out4[1] = c->s.lights_len;
+  out4[2] = (uint32_t)c->s.indices.size() / 3; out4[3] = (uint32_t)c->s.instances.size();
+}
+
+}  // extern "C"
