@@ -1,0 +1,176 @@
+"""Python host binding of librene_hip.so (the C ABI of include/rene_hip.h).
+
+The render path has NO CPU fallback: if the HIP library is missing or no GPU is visible, every
+entry point raises.  (The CPU restatement under oracle/ is test infrastructure and is never
+imported from here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import abi
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(_CSRC, "librene_hip.so")
+_LIB = None
+
+
+class ReneError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"{abi.STATUS_NAMES.get(code, code)}: {message}")
+        self.code = code
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", _CSRC, "-j4"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise ReneError(-3, f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(there is no CPU fallback for the render path)")
+    L = C.CDLL(LIB_PATH)
+    vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int
+    L.rene_create.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(abi.Opts), C.POINTER(vp)]
+    L.rene_render.argtypes = [vp, u32, u32]
+    L.rene_sync.argtypes = [vp]
+    L.rene_download.argtypes = [vp, i32, i32, vp, C.c_size_t]
+    L.rene_reset.argtypes = [vp]
+    L.rene_framebuffer.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.rene_get_stats.argtypes = [vp, C.POINTER(abi.Stats)]
+    L.rene_trace.argtypes = [vp, i32, C.c_size_t, vp, vp, C.c_float, C.c_float, vp]
+    L.rene_destroy.argtypes = [vp]
+    L.rene_destroy.restype = None
+    L.rene_last_error.restype = C.c_char_p
+    L.rene_abi_version.restype = u32
+    L.rene_to_rgb8.argtypes = [vp, C.c_size_t, u32, vp]
+    L.rene_to_rgb8.restype = None
+    L.rene_to_aov8.argtypes = [vp, C.c_size_t, u32, i32, vp]
+    L.rene_to_aov8.restype = None
+    L.rene_frame_seeds.argtypes = [u32, u32, u32, vp]
+    L.rene_frame_seeds.restype = None
+    L.rene_scene_load_pbrt.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.rene_scene_parse_pbrt.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(vp)]
+    L.rene_scene_get_desc.argtypes = [vp]
+    L.rene_scene_get_desc.restype = C.POINTER(abi.SceneDesc)
+    L.rene_scene_film_filename.argtypes = [vp]
+    L.rene_scene_film_filename.restype = C.c_char_p
+    L.rene_scene_free.argtypes = [vp]
+    L.rene_scene_free.restype = None
+    if L.rene_abi_version() != abi.ABI_VERSION:
+        raise ReneError(-1, "librene_hip.so ABI version differs from rene_amd.abi")
+    _LIB = L
+    return L
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise ReneError(rc, lib().rene_last_error().decode(errors="replace"))
+
+
+HIT_DTYPE = np.dtype([("t", np.float32), ("u", np.float32), ("v", np.float32),
+                      ("instance", np.uint32), ("primitive", np.uint32)])
+
+
+class Renderer:
+    """One render context on one GPU: upload once, render frame ranges, read the 3 layers back
+    (rene/src/main.rs:513, 1315-1397, 1453-1623)."""
+
+    def __init__(self, scene, seed: int = abi.DEFAULT_SEED, device: int = 0, flags: int = 0,
+                 shard_mode: int = abi.SHARD_TILES, shard_rank: int = 0, shard_count: int = 1,
+                 framebuffer_ptr: int | None = None, stream_ptr: int | None = None):
+        self._h = C.c_void_p()
+        packed = scene if hasattr(scene, "byref") else scene.to_desc()
+        self._packed = packed
+        o = abi.Opts()
+        o.struct_size = C.sizeof(abi.Opts)
+        o.seed, o.device, o.flags = seed & 0xFFFFFFFF, device, flags
+        o.shard_mode, o.shard_rank, o.shard_count = shard_mode, shard_rank, shard_count
+        o.framebuffer = framebuffer_ptr
+        o.stream = stream_ptr
+        _check(lib().rene_create(packed.byref(), C.byref(o), C.byref(self._h)))
+        self.xres, self.yres = packed.xres, packed.yres
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render(self, first_frame: int, n_frames: int):
+        _check(lib().rene_render(self._h, first_frame, n_frames))
+
+    def sync(self):
+        _check(lib().rene_sync(self._h))
+
+    def reset(self):
+        _check(lib().rene_reset(self._h))
+
+    def download(self, layer: int = abi.LAYER_RADIANCE, channels: int = 3) -> np.ndarray:
+        out = np.empty((self.yres, self.xres, channels), dtype=np.float32)
+        _check(lib().rene_download(self._h, layer, channels, out.ctypes.data_as(C.c_void_p), out.size))
+        return out
+
+    def stats(self) -> abi.Stats:
+        st = abi.Stats()
+        _check(lib().rene_get_stats(self._h, C.byref(st)))
+        return st
+
+    def framebuffer(self) -> tuple[int, int]:
+        p, n = C.c_void_p(), C.c_size_t()
+        _check(lib().rene_framebuffer(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def trace(self, origins, directions, tmin: float = 0.001, tmax: float = 1e5, which: int = 0) -> np.ndarray:
+        o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
+        if o.shape != d.shape:
+            raise ValueError("origins and directions differ in shape")
+        out = np.zeros(o.shape[0], dtype=HIT_DTYPE)
+        _check(lib().rene_trace(self._h, which, o.shape[0], o.ctypes.data_as(C.c_void_p),
+                                d.ctypes.data_as(C.c_void_p), tmin, tmax, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+
+def to_rgb8(sums: np.ndarray, n_samples: int) -> np.ndarray:
+    """average + gamma + quantise (rene/src/main.rs:1758-1792)."""
+    a = np.ascontiguousarray(sums, dtype=np.float32)
+    out = np.empty(a.shape, dtype=np.uint8)
+    lib().rene_to_rgb8(a.ctypes.data_as(C.c_void_p), a.size, n_samples, out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def to_aov8(sums: np.ndarray, n_samples: int, is_normal: bool) -> np.ndarray:
+    a = np.ascontiguousarray(sums, dtype=np.float32)
+    out = np.empty(a.shape, dtype=np.uint8)
+    lib().rene_to_aov8(a.ctypes.data_as(C.c_void_p), a.size, n_samples, int(is_normal), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def frame_seeds(master_seed: int, first_frame: int, n: int) -> np.ndarray:
+    out = np.empty(n, dtype=np.uint32)
+    lib().rene_frame_seeds(master_seed & 0xFFFFFFFF, first_frame, n, out.ctypes.data_as(C.c_void_p))
+    return out

@@ -1,0 +1,85 @@
+// device_math.h -- small fp32 vector helpers + the PCG32si stream for gfx950 device code.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rene {
+
+#define RENE_DEV __device__ __forceinline__
+
+constexpr float kPi = 3.14159265358979323846f;
+constexpr float kInvPi = 0.318309886183790671538f;
+constexpr float kTau = 6.28318530717958647692f;
+
+struct f3 {
+  float x, y, z;
+};
+RENE_DEV f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
+RENE_DEV f3 splat(float s) { return f3{s, s, s}; }
+RENE_DEV f3 operator+(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+RENE_DEV f3 operator-(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+RENE_DEV f3 operator-(f3 a) { return {-a.x, -a.y, -a.z}; }
+RENE_DEV f3 operator*(f3 a, f3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+RENE_DEV f3 operator*(f3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+RENE_DEV f3 operator*(float s, f3 a) { return {a.x * s, a.y * s, a.z * s}; }
+RENE_DEV f3 operator/(f3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+RENE_DEV f3 operator/(f3 a, f3 b) { return {a.x / b.x, a.y / b.y, a.z / b.z}; }
+RENE_DEV float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RENE_DEV f3 cross(f3 a, f3 b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+RENE_DEV float length_squared(f3 a) { return dot(a, a); }
+RENE_DEV float length(f3 a) { return sqrtf(dot(a, a)); }
+RENE_DEV f3 normalize(f3 a) { return a / length(a); }
+RENE_DEV float max_element(f3 a) { return fmaxf(a.x, fmaxf(a.y, a.z)); }
+RENE_DEV bool is_zero(f3 a) { return a.x == 0.0f && a.y == 0.0f && a.z == 0.0f; }
+RENE_DEV f3 sqrt3(f3 a) { return {sqrtf(a.x), sqrtf(a.y), sqrtf(a.z)}; }
+RENE_DEV float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }  // GLSL FClamp
+
+// column-major 4x4 (glam Mat4) times point / vector; no perspective divide (camera.rs:79-83)
+RENE_DEV f3 m4_point(const float* m, f3 p) {
+  return {m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12], m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
+          m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14]};
+}
+RENE_DEV f3 m4_vector(const float* m, f3 p) {
+  return {m[0] * p.x + m[4] * p.y + m[8] * p.z, m[1] * p.x + m[5] * p.y + m[9] * p.z,
+          m[2] * p.x + m[6] * p.y + m[10] * p.z};
+}
+// 3x4 affine stored as x,y,z,w column vectors
+RENE_DEV f3 aff_point(const float* m, f3 p) {
+  return {p.x * m[0] + p.y * m[3] + p.z * m[6] + m[9], p.x * m[1] + p.y * m[4] + p.z * m[7] + m[10],
+          p.x * m[2] + p.y * m[5] + p.z * m[8] + m[11]};
+}
+RENE_DEV f3 aff_vector(const float* m, f3 p) {
+  return {p.x * m[0] + p.y * m[3] + p.z * m[6], p.x * m[1] + p.y * m[4] + p.z * m[7],
+          p.x * m[2] + p.y * m[5] + p.z * m[8]};
+}
+
+// ---- PCG32si, rene-shader/src/rand.rs:4-52 (integer-exact) -------------------------------------------
+struct Pcg {
+  uint32_t state;
+};
+RENE_DEV void pcg_step(Pcg& r) { r.state = r.state * 747796405u + 2891336453u; }
+RENE_DEV Pcg pcg_new(uint32_t seed) {  // rand.rs:24-30
+  Pcg r{seed};
+  pcg_step(r);
+  r.state += seed;
+  pcg_step(r);
+  return r;
+}
+RENE_DEV uint32_t pcg_u32(Pcg& r) {  // rand.rs:19-22, 32-36
+  uint32_t s = r.state;
+  pcg_step(r);
+  uint32_t word = ((s >> ((s >> 28) + 4u)) ^ s) * 277803737u;
+  return (word >> 22) ^ word;
+}
+RENE_DEV float pcg_f32(Pcg& r) {  // rand.rs:38-47
+  return (1.0f / 16777216.0f) * (float)(pcg_u32(r) >> 8);
+}
+RENE_DEV float pcg_range(Pcg& r, float lo, float hi) { return lo + (hi - lo) * pcg_f32(r); }
+
+// sin/cos of 2*pi*x for x in [0,1): v_sin_f32 / v_cos_f32 take their argument in revolutions
+RENE_DEV float sin_2pi(float x) { return __builtin_amdgcn_sinf(x); }
+RENE_DEV float cos_2pi(float x) { return __builtin_amdgcn_cosf(x); }
+
+}  // namespace rene

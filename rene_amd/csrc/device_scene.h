@@ -1,0 +1,162 @@
+// device_scene.h -- HBM layout of a flattened scene, shared by the host packer and the kernels.
+//
+// The reference keeps object-space vertex/index buffers plus Vulkan TLAS/BLAS objects
+// (rene/src/main.rs:2910-3336).  CDNA4 has no RT hardware, so the layout here is designed for a
+// software traversal with 16-byte vector loads:
+//   * instancing is flattened: every triangle is stored once per instance in WORLD space
+//     (288 GB of HBM makes duplication cheap; one-level traversal has no ray re-transform);
+//   * a BVH2 node is one 64-byte record (both child boxes + both links) = one cache line;
+//   * a primitive's intersection record is 48 bytes (3 x float4), its shading record 64 bytes,
+//     both stored in BVH leaf order so a leaf's primitives are contiguous.
+#pragma once
+#include <stdint.h>
+
+namespace rene {
+
+// ---- BVH2 node: 4 x float4 ------------------------------------------------------------------------
+//   q0 = lo0.x lo0.y lo0.z hi0.x
+//   q1 = hi0.y hi0.z lo1.x lo1.y
+//   q2 = lo1.z hi1.x hi1.y hi1.z
+//   q3 = bits(child0) bits(child1) 0 0
+// child word: bit31 = 0 -> inner node index
+//             bit31 = 1 -> leaf: bit30 = sphere leaf, bits29..26 = count-1, bits25..0 = first slot
+struct Node {
+  float q[16];
+};
+constexpr uint32_t LEAF_BIT = 0x80000000u;
+constexpr uint32_t SPHERE_BIT = 0x40000000u;
+constexpr uint32_t LEAF_COUNT_SHIFT = 26;
+constexpr uint32_t LEAF_FIRST_MASK = (1u << 26) - 1u;
+constexpr uint32_t MAX_LEAF_PRIMS = 16;
+
+// ---- primitive intersection record: 3 x float4 (Moeller-Trumbore operands) -----------------------
+//   q0 = p0.x p0.y p0.z e1.x
+//   q1 = e1.y e1.z e2.x e2.y
+//   q2 = e2.z bits(instance) bits(primitive id within its mesh) bits(sphere index or ~0)
+// For a sphere slot q0/q1 are unused and q2.w indexes the sphere table.
+struct PrimIsect {
+  float q[12];
+};
+
+// ---- primitive shading record: 4 x float4 ------------------------------------------------------------
+//   q0 = n0.xyz uv0.x   q1 = n1.xyz uv0.y   q2 = n2.xyz uv1.x   q3 = uv1.y uv2.x uv2.y 0
+// n_i = world_to_object^T * vertex normal (not normalised; linear, so interpolation commutes with
+// the transform, rene-shader/src/lib.rs:931-949).  If all three vertex normals are exactly zero the
+// transformed geometric normal cross(v1-v0, v2-v0) is stored three times (lib.rs:931-932).
+struct PrimShade {
+  float q[16];
+};
+
+// ---- emitter-pdf record, one per slot of the emitter-only structure -------------------------------
+//   triangle: n.xyz (normalised world face normal), area      (lib.rs:1004-1036)
+struct EmitPdf {
+  float q[4];
+};
+
+// ---- sphere table: object_to_world and world_to_object as 3x4 column vectors ----------------------
+struct Sphere {
+  float o2w[12];
+  float w2o[12];
+};
+
+// ---- per-instance data (IndexData, lib.rs:108-118, plus what the hit shaders look up) -------------
+struct Inst {
+  uint32_t material;
+  uint32_t area_light;
+  float primitive_count;   // as f32, lib.rs:1043
+  uint32_t material_type;  // copy of materials[material].type
+  float kd[4];             // Matte + Solid texture shortcut: albedo; .w = 1 if the shortcut is valid
+  float emit[4];           // area light radiance; .w = 1 if area light is non-null
+};
+
+// ---- emit objects (EnumSurfaceSample, surface_sample.rs:20-33) --------------------------------------
+struct EmitObject {
+  uint32_t type;        // 0 triangle, 1 sphere
+  uint32_t first_tri;   // into emit_tris (world-space, ORIGINAL mesh order: `next_u32 % count`)
+  uint32_t prim_count;
+  uint32_t pad;
+  float matrix[12];     // spheres: object_to_world
+};
+// world-space emitter triangle for sampling: p0.xyz p1.x | p1.yz p2.xy | p2.z 0 0 0
+struct EmitTri {
+  float q[12];
+};
+
+struct Material {  // rene_material padded to 64 B
+  uint32_t type;
+  uint32_t u0[4];
+  uint32_t u1[4];
+  float v0[4];
+  uint32_t pad[3];
+};
+struct Texture {  // rene_texture padded to 48 B
+  uint32_t type;
+  uint32_t u0[4];
+  float v0[4];
+  uint32_t pad[3];
+};
+struct Light {  // rene_light (distant): dir.xyz, 0, L.rgb, 0
+  float dir[4];
+  float L[4];
+};
+struct ImageRef {
+  uint64_t offset;  // float offset into the image pool
+  uint32_t width, height;
+};
+
+// one traversable structure
+struct Accel {
+  const Node* nodes;
+  const PrimIsect* isect;
+  uint32_t n_nodes;
+  uint32_t n_slots;
+};
+
+// everything a kernel needs, passed by value (lives in SGPRs / kernarg)
+struct SceneView {
+  Accel main;
+  Accel emit;
+  const PrimShade* shade;     // main structure, slot order
+  const EmitPdf* emit_pdf;    // emitter structure, slot order
+  const Sphere* spheres;
+  const Inst* insts;
+  const EmitObject* emit_objects;
+  const EmitTri* emit_tris;
+  const Material* materials;
+  const Texture* textures;
+  const Light* lights;
+  const ImageRef* images;
+  const float* image_pool;
+  float c2w[16];
+  float proj_inv[16];
+  float bg_matrix[16];
+  float bg_color[4];
+  uint32_t bg_texture;
+  uint32_t lights_len;
+  uint32_t emit_object_len;
+  uint32_t width, height;
+};
+
+// scene feature bits -> kernel specialisation
+enum : uint32_t {
+  FEAT_SPHERES = 1u << 0,      // any sphere instance
+  FEAT_GENERAL_BSDF = 1u << 1, // any material other than None / Matte
+  FEAT_TEXTURES = 1u << 2,     // any non-solid texture reachable (checkerboard / scale / imagemap)
+  FEAT_LIGHTS = 1u << 3,       // distant lights
+  FEAT_BACKGROUND = 1u << 4,   // non-black background
+  FEAT_MULTI_LOBE = 1u << 5,   // Plastic / Uber (more than one lobe)
+};
+
+struct RenderParams {
+  float* framebuffer;      // [3][H][W][4]
+  const uint32_t* seeds;   // n_frames frame seeds
+  uint32_t* work_counter;  // next work id
+  unsigned long long* counters;  // 9 x u64
+  uint32_t n_frames;
+  uint32_t n_work;         // work ids: owned tiles * 1024
+  uint32_t shard_rank, shard_count;  // tile sharding (shard_count == 1: all tiles)
+  uint32_t tiles_x, n_tiles;
+  uint32_t flags;
+};
+
+}  // namespace rene

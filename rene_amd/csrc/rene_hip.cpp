@@ -1,0 +1,449 @@
+// rene_hip.cpp -- implementation of the C ABI declared in include/rene_hip.h (render path part).
+// Compiled with hipcc; owns all device memory; never throws or aborts across the boundary.
+#include "../../include/rene_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "device_scene.h"
+#include "kernels.h"
+#include "scene_pack.h"
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const std::string& msg) {
+  g_error = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess)                                                                          \
+      return fail(e_ == hipErrorOutOfMemory ? RENE_ERR_OUT_OF_MEMORY : RENE_ERR_DEVICE,            \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                              \
+  } while (0)
+
+// PCG32si restated for the host-side seed schedule (rene-shader/src/rand.rs:4-52)
+struct HostPcg {
+  uint32_t s;
+  explicit HostPcg(uint32_t seed) : s(seed) {
+    step();
+    s += seed;
+    step();
+  }
+  void step() { s = s * 747796405u + 2891336453u; }
+  uint32_t next() {
+    uint32_t o = s;
+    step();
+    uint32_t w = ((o >> ((o >> 28) + 4u)) ^ o) * 277803737u;
+    return (w >> 22) ^ w;
+  }
+};
+
+}  // namespace
+
+struct rene_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  rene_opts opts{};
+  std::vector<void*> allocations;
+  rene::SceneView view{};
+  rene::LaunchConfig cfg{};
+  uint32_t width = 0, height = 0, tiles_x = 0, n_tiles = 0, n_work = 0;
+  float* fb = nullptr;
+  bool own_fb = false;
+  size_t fb_floats = 0;
+  uint32_t* d_work_counter = nullptr;
+  unsigned long long* d_counters = nullptr;
+  // per-launch resources that must outlive the asynchronous launch
+  struct Pending {
+    hipEvent_t start, stop;
+    uint32_t* d_seeds;
+  };
+  std::deque<Pending> pending;
+  uint64_t frames = 0, launches = 0;
+  double kernel_ms = 0.0, last_ms = 0.0;
+  // seed schedule cache: seeds[k] = k-th next_u32 of PCG32si::new(master)
+  std::vector<uint32_t> seed_cache;
+  HostPcg seed_gen{0};
+
+  template <class T>
+  int upload(const std::vector<T>& v, const T** out) {
+    size_t bytes = std::max<size_t>(1, v.size()) * sizeof(T);
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, bytes));
+    allocations.push_back(p);
+    if (!v.empty()) HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    else HIP_TRY(hipMemset(p, 0, bytes));
+    *out = static_cast<const T*>(p);
+    return RENE_OK;
+  }
+
+  int drain() {  // wait for the stream and fold finished launches into the timing totals
+    HIP_TRY(hipStreamSynchronize(stream));
+    while (!pending.empty()) {
+      Pending& p = pending.front();
+      float ms = 0.0f;
+      HIP_TRY(hipEventElapsedTime(&ms, p.start, p.stop));
+      kernel_ms += ms;
+      last_ms = ms;
+      hipEventDestroy(p.start);
+      hipEventDestroy(p.stop);
+      hipFree(p.d_seeds);
+      pending.pop_front();
+    }
+    return RENE_OK;
+  }
+};
+
+extern "C" {
+
+const char* rene_last_error(void) { return g_error.c_str(); }
+uint32_t rene_abi_version(void) { return RENE_ABI_VERSION; }
+
+void rene_frame_seeds(uint32_t master_seed, uint32_t first_frame, uint32_t n, uint32_t* out) {
+  HostPcg g(master_seed);
+  for (uint32_t k = 0; k < first_frame; ++k) g.next();
+  for (uint32_t k = 0; k < n; ++k) out[k] = g.next();
+}
+
+int rene_create(const rene_scene_desc* scene, const rene_opts* opts, rene_ctx** out) {
+  if (!scene || !out) return fail(RENE_ERR_INVALID_ARGUMENT, "rene_create: NULL argument");
+  *out = nullptr;
+  rene_opts o{};
+  o.struct_size = sizeof(rene_opts);
+  o.seed = RENE_DEFAULT_SEED;
+  if (opts) {
+    if (opts->struct_size != sizeof(rene_opts))
+      return fail(RENE_ERR_INVALID_ARGUMENT, "rene_opts.struct_size mismatch (ABI skew)");
+    o = *opts;
+  }
+  if (o.shard_count == 0) o.shard_count = 1;
+  if (o.shard_rank >= o.shard_count) return fail(RENE_ERR_INVALID_ARGUMENT, "shard_rank >= shard_count");
+  if (o.shard_mode > RENE_SHARD_FRAMES) return fail(RENE_ERR_INVALID_ARGUMENT, "unknown shard_mode");
+
+  rene::PackedScene ps;
+  std::string err;
+  int rc = rene::pack_scene(scene, ps, err);
+  if (rc != RENE_OK) return fail(rc, err);
+
+  int n_dev = 0;
+  HIP_TRY(hipGetDeviceCount(&n_dev));
+  if (n_dev <= 0) return fail(RENE_ERR_DEVICE, "no HIP device visible (the render path has no CPU fallback)");
+  if (o.device < 0 || o.device >= n_dev) return fail(RENE_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+  HIP_TRY(hipSetDevice(o.device));
+
+  std::unique_ptr<rene_ctx> c(new rene_ctx());
+  c->device = o.device;
+  c->opts = o;
+  c->seed_gen = HostPcg(o.seed);
+  c->width = ps.width;
+  c->height = ps.height;
+  struct Cleanup {
+    std::unique_ptr<rene_ctx>& c;
+    bool armed = true;
+    ~Cleanup() {
+      if (armed && c) {
+        rene_ctx* p = c.release();
+        rene_destroy(p);
+      }
+    }
+  } cleanup{c};
+
+  if (o.stream) {
+    c->stream = static_cast<hipStream_t>(o.stream);
+  } else {
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+  }
+
+  rene::SceneView& v = c->view;
+#define UP(vec, field)                              \
+  do {                                              \
+    int rc_ = c->upload(vec, &field);               \
+    if (rc_ != RENE_OK) return rc_;                 \
+  } while (0)
+  UP(ps.main.nodes, v.main.nodes);
+  UP(ps.main.isect, v.main.isect);
+  UP(ps.emit.nodes, v.emit.nodes);
+  UP(ps.emit.isect, v.emit.isect);
+  v.main.n_nodes = (uint32_t)ps.main.nodes.size();
+  v.main.n_slots = (uint32_t)ps.main.isect.size();
+  v.emit.n_nodes = (uint32_t)ps.emit.nodes.size();
+  v.emit.n_slots = (uint32_t)ps.emit.isect.size();
+  UP(ps.shade, v.shade);
+  UP(ps.emit_pdf, v.emit_pdf);
+  UP(ps.spheres, v.spheres);
+  UP(ps.insts, v.insts);
+  UP(ps.emit_objects, v.emit_objects);
+  UP(ps.emit_tris, v.emit_tris);
+  UP(ps.materials, v.materials);
+  UP(ps.textures, v.textures);
+  UP(ps.lights, v.lights);
+  UP(ps.images, v.images);
+  UP(ps.image_pool, v.image_pool);
+#undef UP
+  std::memcpy(v.c2w, ps.uniform.camera_to_world, 64);
+  std::memcpy(v.proj_inv, ps.uniform.projection_inv, 64);
+  std::memcpy(v.bg_matrix, ps.uniform.background_matrix, 64);
+  std::memcpy(v.bg_color, ps.uniform.background_color, 16);
+  v.bg_texture = ps.uniform.background_texture;
+  v.lights_len = (uint32_t)ps.lights.size();                // rene/src/scene.rs:166
+  v.emit_object_len = (uint32_t)ps.emit_objects.size();     // rene/src/main.rs:3279
+  v.width = ps.width;
+  v.height = ps.height;
+
+  // traversal stack: enough for the deeper of the two trees, in LDS, [depth][256 lanes]
+  uint32_t depth = std::max(ps.main.depth, ps.emit.depth);
+  uint32_t stack = 16;
+  while (stack < depth) stack += 16;
+  if (stack > 96) return fail(RENE_ERR_UNSUPPORTED, "BVH deeper than the 96-entry traversal stack");
+  c->cfg.features = ps.features;
+  c->cfg.stack_depth = stack;
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, o.device));
+  c->cfg.grid = (uint32_t)prop.multiProcessorCount * 8u;  // persistent launch; surplus blocks find no work
+
+  c->tiles_x = (ps.width + RENE_TILE_SIZE - 1) / RENE_TILE_SIZE;
+  uint32_t tiles_y = (ps.height + RENE_TILE_SIZE - 1) / RENE_TILE_SIZE;
+  c->n_tiles = c->tiles_x * tiles_y;
+  uint32_t tile_rank = 0, tile_count = 1;
+  if (o.shard_mode == RENE_SHARD_TILES) {
+    tile_rank = o.shard_rank;
+    tile_count = o.shard_count;
+  }
+  uint32_t owned = c->n_tiles > tile_rank ? (c->n_tiles - tile_rank + tile_count - 1) / tile_count : 0;
+  c->n_work = owned * RENE_TILE_SIZE * RENE_TILE_SIZE;
+
+  c->fb_floats = (size_t)3 * ps.width * ps.height * 4;
+  if (o.framebuffer) {
+    c->fb = static_cast<float*>(o.framebuffer);
+  } else {
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->fb), c->fb_floats * sizeof(float)));
+    c->own_fb = true;
+  }
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_work_counter), sizeof(uint32_t)));
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_counters), 16 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemsetAsync(c->fb, 0, c->fb_floats * sizeof(float), c->stream));  // main.rs:1229-1237
+  HIP_TRY(hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+
+  cleanup.armed = false;
+  *out = c.release();
+  return RENE_OK;
+}
+
+void rene_destroy(rene_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  if (c->stream) hipStreamSynchronize(c->stream);
+  for (auto& p : c->pending) {
+    hipEventDestroy(p.start);
+    hipEventDestroy(p.stop);
+    hipFree(p.d_seeds);
+  }
+  for (void* p : c->allocations) hipFree(p);
+  if (c->own_fb && c->fb) hipFree(c->fb);
+  if (c->d_work_counter) hipFree(c->d_work_counter);
+  if (c->d_counters) hipFree(c->d_counters);
+  if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int rene_render(rene_ctx* c, uint32_t first_frame, uint32_t n_frames) {
+  if (!c) return fail(RENE_ERR_INVALID_ARGUMENT, "rene_render: NULL context");
+  if (n_frames == 0) return RENE_OK;
+  if ((uint64_t)first_frame + n_frames > 0xffffffffull) return fail(RENE_ERR_INVALID_ARGUMENT, "frame range overflows u32");
+  HIP_TRY(hipSetDevice(c->device));
+  // seed schedule: frame k -> k-th next_u32 of PCG32si::new(master)
+  while (c->seed_cache.size() < (size_t)first_frame + n_frames) c->seed_cache.push_back(c->seed_gen.next());
+  std::vector<uint32_t> seeds;
+  seeds.reserve(n_frames);
+  for (uint32_t k = 0; k < n_frames; ++k) {
+    uint32_t f = first_frame + k;
+    if (c->opts.shard_mode == RENE_SHARD_FRAMES && c->opts.shard_count > 1 &&
+        f % c->opts.shard_count != c->opts.shard_rank)
+      continue;
+    seeds.push_back(c->seed_cache[f]);
+  }
+  c->frames += n_frames;
+  if (seeds.empty() || c->n_work == 0) return RENE_OK;
+
+  rene_ctx::Pending pend{};
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&pend.d_seeds), seeds.size() * sizeof(uint32_t)));
+  // pageable source: the copy is staged before hipMemcpyAsync returns, so `seeds` may die
+  hipError_t e = hipMemcpyAsync(pend.d_seeds, seeds.data(), seeds.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(c->d_work_counter, 0, sizeof(uint32_t), c->stream);
+  if (e == hipSuccess) e = hipEventCreate(&pend.start);
+  if (e == hipSuccess) e = hipEventCreate(&pend.stop);
+  if (e != hipSuccess) {
+    hipFree(pend.d_seeds);
+    return fail(RENE_ERR_DEVICE, std::string("rene_render setup: ") + hipGetErrorString(e));
+  }
+  rene::RenderParams P{};
+  P.framebuffer = c->fb;
+  P.seeds = pend.d_seeds;
+  P.work_counter = c->d_work_counter;
+  P.counters = c->d_counters;
+  P.n_frames = (uint32_t)seeds.size();
+  P.n_work = c->n_work;
+  P.shard_rank = c->opts.shard_mode == RENE_SHARD_TILES ? c->opts.shard_rank : 0;
+  P.shard_count = c->opts.shard_mode == RENE_SHARD_TILES ? c->opts.shard_count : 1;
+  P.tiles_x = c->tiles_x;
+  P.n_tiles = c->n_tiles;
+  P.flags = c->opts.flags;
+  rene::LaunchConfig cfg = c->cfg;
+  uint32_t blocks_needed = (c->n_work + rene::render_block_size() - 1) / rene::render_block_size();
+  cfg.grid = std::max(1u, std::min(cfg.grid, blocks_needed));
+  hipEventRecord(pend.start, c->stream);
+  e = rene::launch_render(cfg, c->view, P, c->stream);
+  hipEventRecord(pend.stop, c->stream);
+  c->pending.push_back(pend);
+  c->launches++;
+  if (e != hipSuccess) return fail(RENE_ERR_DEVICE, std::string("render launch: ") + hipGetErrorString(e));
+  if (c->pending.size() > 64) return c->drain();
+  return RENE_OK;
+}
+
+int rene_sync(rene_ctx* c) {
+  if (!c) return fail(RENE_ERR_INVALID_ARGUMENT, "rene_sync: NULL context");
+  HIP_TRY(hipSetDevice(c->device));
+  return c->drain();
+}
+
+int rene_reset(rene_ctx* c) {
+  if (!c) return fail(RENE_ERR_INVALID_ARGUMENT, "rene_reset: NULL context");
+  HIP_TRY(hipSetDevice(c->device));
+  int rc = c->drain();
+  if (rc != RENE_OK) return rc;
+  HIP_TRY(hipMemsetAsync(c->fb, 0, c->fb_floats * sizeof(float), c->stream));
+  HIP_TRY(hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->frames = 0;
+  c->launches = 0;
+  c->kernel_ms = 0.0;
+  c->last_ms = 0.0;
+  return RENE_OK;
+}
+
+int rene_framebuffer(rene_ctx* c, void** device_ptr, size_t* n_floats) {
+  if (!c || !device_ptr) return fail(RENE_ERR_INVALID_ARGUMENT, "rene_framebuffer: NULL argument");
+  *device_ptr = c->fb;
+  if (n_floats) *n_floats = c->fb_floats;
+  return RENE_OK;
+}
+
+int rene_download(rene_ctx* c, int layer, int channels, float* dst, size_t dst_floats) {
+  if (!c || !dst) return fail(RENE_ERR_INVALID_ARGUMENT, "rene_download: NULL argument");
+  if (layer < 0 || layer >= RENE_LAYER_COUNT) return fail(RENE_ERR_INVALID_ARGUMENT, "layer out of range");
+  if (channels != 3 && channels != 4) return fail(RENE_ERR_INVALID_ARGUMENT, "channels must be 3 or 4");
+  size_t n = (size_t)c->width * c->height;
+  if (dst_floats < n * (size_t)channels) return fail(RENE_ERR_INVALID_ARGUMENT, "destination too small");
+  HIP_TRY(hipSetDevice(c->device));
+  int rc = c->drain();
+  if (rc != RENE_OK) return rc;
+  const float* src = c->fb + (size_t)layer * n * 4;
+  if (channels == 4) {
+    HIP_TRY(hipMemcpy(dst, src, n * 4 * sizeof(float), hipMemcpyDeviceToHost));
+    return RENE_OK;
+  }
+  std::vector<float> tmp(n * 4);
+  HIP_TRY(hipMemcpy(tmp.data(), src, n * 4 * sizeof(float), hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < n; ++i) {  // f32_4_to_3, rene/src/main.rs:1749-1756
+    dst[3 * i] = tmp[4 * i];
+    dst[3 * i + 1] = tmp[4 * i + 1];
+    dst[3 * i + 2] = tmp[4 * i + 2];
+  }
+  return RENE_OK;
+}
+
+int rene_get_stats(rene_ctx* c, rene_stats* out) {
+  if (!c || !out) return fail(RENE_ERR_INVALID_ARGUMENT, "rene_get_stats: NULL argument");
+  HIP_TRY(hipSetDevice(c->device));
+  int rc = c->drain();
+  if (rc != RENE_OK) return rc;
+  unsigned long long h[8];
+  HIP_TRY(hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
+  std::memset(out, 0, sizeof(*out));
+  out->rays_closest = h[0];
+  out->rays_shadow = h[1];
+  out->rays_emitter = h[2];
+  out->paths = h[3];
+  out->hits = h[4];
+  out->bounces = h[4];
+  out->adds = h[5];
+  out->node_visits = h[6];
+  out->prim_tests = h[7];
+  out->frames = c->frames;
+  out->launches = c->launches;
+  out->kernel_ms = c->kernel_ms;
+  out->last_launch_ms = c->last_ms;
+  return RENE_OK;
+}
+
+int rene_trace(rene_ctx* c, int which, size_t n, const float* origins, const float* directions, float tmin,
+               float tmax, rene_hit* out) {
+  if (!c || (n && (!origins || !directions || !out))) return fail(RENE_ERR_INVALID_ARGUMENT, "rene_trace: NULL argument");
+  if (which != 0 && which != 1) return fail(RENE_ERR_INVALID_ARGUMENT, "which must be 0 (main) or 1 (emitters)");
+  if (n == 0) return RENE_OK;
+  if (n > 0x7fffffffull) return fail(RENE_ERR_INVALID_ARGUMENT, "too many rays in one batch");
+  HIP_TRY(hipSetDevice(c->device));
+  float *d_o = nullptr, *d_d = nullptr;
+  rene_hit* d_h = nullptr;
+  auto cleanup = [&]() {
+    hipFree(d_o);
+    hipFree(d_d);
+    hipFree(d_h);
+  };
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_o), n * 12);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_d), n * 12);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_h), n * sizeof(rene_hit));
+  if (e == hipSuccess) e = hipMemcpyAsync(d_o, origins, n * 12, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_d, directions, n * 12, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = rene::launch_trace(c->cfg, c->view, which, (uint32_t)n, d_o, d_d, tmin, tmax, d_h, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(out, d_h, n * sizeof(rene_hit), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  cleanup();
+  if (e != hipSuccess) return fail(RENE_ERR_DEVICE, std::string("rene_trace: ") + hipGetErrorString(e));
+  return RENE_OK;
+}
+
+// ---- output transform, rene/src/main.rs:1758-1810 ---------------------------------------------------------
+static float gamma_correct(float v) {  // main.rs:1768-1774
+  if (v <= 0.0031308f) return 12.92f * v;
+  return 1.055f * std::pow(v, 1.0f / 2.4f) - 0.055f;
+}
+static uint8_t sat_u8(float v) {  // Rust `as u8`: saturating, NaN -> 0
+  if (!(v > 0.0f)) return 0;
+  if (v >= 255.0f) return 255;
+  return (uint8_t)v;
+}
+void rene_to_rgb8(const float* sums, size_t n_floats, uint32_t n_samples, uint8_t* out) {
+  const float denom = (float)n_samples;
+  for (size_t i = 0; i < n_floats; ++i) {
+    float v = sums[i] / denom;                              // average, main.rs:1758-1764
+    float r = std::round(255.0f * gamma_correct(v));        // to_rgb8, main.rs:1785-1792
+    out[i] = sat_u8(std::fmin(std::fmax(r, 0.0f), 255.0f));
+  }
+}
+void rene_to_aov8(const float* sums, size_t n_floats, uint32_t n_samples, int is_normal, uint8_t* out) {
+  const float denom = (float)n_samples;
+  for (size_t i = 0; i < n_floats; ++i) {
+    float v = sums[i] / denom;
+    if (is_normal) v = v * 0.5f + 0.5f;                                 // to_aov_normal, main.rs:1803-1810
+    out[i] = sat_u8(256.0f * std::fmin(std::fmax(v, 0.0f), 0.999f));  // to_aov, main.rs:1794-1801
+  }
+}
+
+}  // extern "C"

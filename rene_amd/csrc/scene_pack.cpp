@@ -1,0 +1,507 @@
+// scene_pack.cpp -- see scene_pack.h.  Pure host C++ (no HIP calls).
+#include "scene_pack.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace rene {
+namespace {
+
+struct V3 {
+  float x, y, z;
+};
+inline V3 sub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 cross(V3 a, V3 b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+inline float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+struct Box {
+  float lo[3], hi[3];
+  void reset() {
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = std::numeric_limits<float>::infinity();
+      hi[a] = -std::numeric_limits<float>::infinity();
+    }
+  }
+  void grow(V3 p) {
+    lo[0] = std::min(lo[0], p.x); hi[0] = std::max(hi[0], p.x);
+    lo[1] = std::min(lo[1], p.y); hi[1] = std::max(hi[1], p.y);
+    lo[2] = std::min(lo[2], p.z); hi[2] = std::max(hi[2], p.z);
+  }
+  void grow(const Box& b) {
+    for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], b.lo[a]); hi[a] = std::max(hi[a], b.hi[a]); }
+  }
+  float half_area() const {
+    float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    return dx * dy + dy * dz + dz * dx;
+  }
+};
+
+// 3x4 affine as column vectors (glam Affine3A)
+struct Aff {
+  V3 x, y, z, w;
+};
+inline Aff aff_from(const float* m) {
+  return {{m[0], m[1], m[2]}, {m[3], m[4], m[5]}, {m[6], m[7], m[8]}, {m[9], m[10], m[11]}};
+}
+inline V3 xform_point(const Aff& m, V3 p) {
+  return {p.x * m.x.x + p.y * m.y.x + p.z * m.z.x + m.w.x, p.x * m.x.y + p.y * m.y.y + p.z * m.z.y + m.w.y,
+          p.x * m.x.z + p.y * m.y.z + p.z * m.z.z + m.w.z};
+}
+bool aff_inverse(const Aff& m, Aff& out) {
+  double a[3][3] = {{m.x.x, m.y.x, m.z.x}, {m.x.y, m.y.y, m.z.y}, {m.x.z, m.y.z, m.z.z}};
+  double c00 = a[1][1] * a[2][2] - a[1][2] * a[2][1];
+  double c01 = a[1][2] * a[2][0] - a[1][0] * a[2][2];
+  double c02 = a[1][0] * a[2][1] - a[1][1] * a[2][0];
+  double det = a[0][0] * c00 + a[0][1] * c01 + a[0][2] * c02;
+  if (det == 0.0 || !std::isfinite(det)) return false;
+  double id = 1.0 / det;
+  double inv[3][3];
+  inv[0][0] = c00 * id;
+  inv[0][1] = (a[0][2] * a[2][1] - a[0][1] * a[2][2]) * id;
+  inv[0][2] = (a[0][1] * a[1][2] - a[0][2] * a[1][1]) * id;
+  inv[1][0] = c01 * id;
+  inv[1][1] = (a[0][0] * a[2][2] - a[0][2] * a[2][0]) * id;
+  inv[1][2] = (a[0][2] * a[1][0] - a[0][0] * a[1][2]) * id;
+  inv[2][0] = c02 * id;
+  inv[2][1] = (a[0][1] * a[2][0] - a[0][0] * a[2][1]) * id;
+  inv[2][2] = (a[0][0] * a[1][1] - a[0][1] * a[1][0]) * id;
+  double t[3] = {m.w.x, m.w.y, m.w.z}, it[3];
+  for (int r = 0; r < 3; ++r) it[r] = -(inv[r][0] * t[0] + inv[r][1] * t[1] + inv[r][2] * t[2]);
+  out.x = {(float)inv[0][0], (float)inv[1][0], (float)inv[2][0]};
+  out.y = {(float)inv[0][1], (float)inv[1][1], (float)inv[2][1]};
+  out.z = {(float)inv[0][2], (float)inv[1][2], (float)inv[2][2]};
+  out.w = {(float)it[0], (float)it[1], (float)it[2]};
+  return true;
+}
+// normal transform: (w2o.x . n, w2o.y . n, w2o.z . n)  -- rene-shader/src/lib.rs:944-948
+inline V3 xform_normal(const Aff& w2o, V3 n) { return {dot(w2o.x, n), dot(w2o.y, n), dot(w2o.z, n)}; }
+
+inline float bits_to_float(uint32_t u) {
+  float f;
+  std::memcpy(&f, &u, 4);
+  return f;
+}
+
+// a primitive before BVH ordering
+struct Prim {
+  Box box;
+  PrimIsect isect;
+  PrimShade shade;
+  EmitPdf pdf;
+  bool sphere;
+};
+
+void pad_box(Box& b) {
+  // rays are tested against boxes with a few ulp of slack; make flat boxes (axis-aligned quads)
+  // robust against the rounding of (plane - origin) * inv_dir
+  for (int a = 0; a < 3; ++a) {
+    float m = std::max(std::fabs(b.lo[a]), std::fabs(b.hi[a]));
+    float pad = 2e-6f * m + 1e-7f;
+    b.lo[a] -= pad;
+    b.hi[a] += pad;
+  }
+}
+
+// Binned-SAH BVH2 over `prims`, emitting the 64-byte GPU nodes.  Spheres get leaves of their own.
+struct Builder {
+  const std::vector<Prim>& prims;
+  std::vector<uint32_t> order;
+  std::vector<float> cen;
+  std::vector<Node> nodes;
+  uint32_t max_leaf;
+  uint32_t max_depth = 0;
+
+  Builder(const std::vector<Prim>& p, uint32_t ml) : prims(p), max_leaf(ml) {}
+
+  static void set_child(Node& n, int which, const Box& b, uint32_t word) {
+    float* q = n.q;
+    if (which == 0) {
+      q[0] = b.lo[0]; q[1] = b.lo[1]; q[2] = b.lo[2]; q[3] = b.hi[0]; q[4] = b.hi[1]; q[5] = b.hi[2];
+      q[12] = bits_to_float(word);
+    } else {
+      q[6] = b.lo[0]; q[7] = b.lo[1]; q[8] = b.lo[2]; q[9] = b.hi[0]; q[10] = b.hi[1]; q[11] = b.hi[2];
+      q[13] = bits_to_float(word);
+    }
+  }
+  static Box empty_box() {
+    Box b;  // lo = +inf, hi = -inf never passes a slab test
+    b.reset();
+    return b;
+  }
+
+  bool leaf_ok(uint32_t first, uint32_t count) const {
+    if (count == 1) return true;
+    if (count > max_leaf) return false;
+    for (uint32_t i = first; i < first + count; ++i)
+      if (prims[order[i]].sphere) return false;
+    return true;
+  }
+  uint32_t leaf_word(uint32_t first, uint32_t count) const {
+    uint32_t w = LEAF_BIT | ((count - 1) << LEAF_COUNT_SHIFT) | first;
+    if (prims[order[first]].sphere) w |= SPHERE_BIT;
+    return w;
+  }
+
+  // splits [first, first+count) and returns mid
+  uint32_t split(uint32_t first, uint32_t count) {
+    Box cb;
+    cb.reset();
+    for (uint32_t i = first; i < first + count; ++i) {
+      const float* c = &cen[3 * order[i]];
+      cb.grow(V3{c[0], c[1], c[2]});
+    }
+    constexpr int NB = 32;
+    int best_axis = -1, best_split = -1;
+    float best_cost = std::numeric_limits<float>::infinity();
+    for (int a = 0; a < 3; ++a) {
+      float ext = cb.hi[a] - cb.lo[a];
+      if (!(ext > 0.0f)) continue;
+      Box bb[NB];
+      uint32_t bc[NB] = {0};
+      for (auto& b : bb) b.reset();
+      float scale = (float)NB / ext;
+      for (uint32_t i = first; i < first + count; ++i) {
+        int bi = std::min(NB - 1, (int)((cen[3 * order[i] + a] - cb.lo[a]) * scale));
+        bb[bi].grow(prims[order[i]].box);
+        bc[bi]++;
+      }
+      float ra[NB];
+      uint32_t rc[NB];
+      Box acc;
+      acc.reset();
+      uint32_t cnt = 0;
+      for (int i = NB - 1; i > 0; --i) {
+        if (bc[i]) acc.grow(bb[i]);
+        cnt += bc[i];
+        ra[i] = cnt ? acc.half_area() : 0.f;
+        rc[i] = cnt;
+      }
+      acc.reset();
+      cnt = 0;
+      for (int i = 0; i < NB - 1; ++i) {
+        if (bc[i]) acc.grow(bb[i]);
+        cnt += bc[i];
+        if (!cnt || !rc[i + 1]) continue;
+        float cost = acc.half_area() * (float)cnt + ra[i + 1] * (float)rc[i + 1];
+        if (cost < best_cost) { best_cost = cost; best_axis = a; best_split = i; }
+      }
+    }
+    uint32_t mid = first + count / 2;
+    if (best_axis >= 0) {
+      float ext = cb.hi[best_axis] - cb.lo[best_axis];
+      float scale = (float)NB / ext;
+      float lo = cb.lo[best_axis];
+      auto* b = order.data() + first;
+      auto* m = std::partition(b, b + count, [&](uint32_t p) {
+        int bi = std::min(NB - 1, (int)((cen[3 * p + best_axis] - lo) * scale));
+        return bi <= best_split;
+      });
+      uint32_t mm = (uint32_t)(m - order.data());
+      if (mm != first && mm != first + count) mid = mm;
+    }
+    return mid;
+  }
+
+  Box range_box(uint32_t first, uint32_t count) const {
+    Box b;
+    b.reset();
+    for (uint32_t i = first; i < first + count; ++i) b.grow(prims[order[i]].box);
+    return b;
+  }
+
+  void build() {
+    uint32_t n = (uint32_t)prims.size();
+    order.resize(n);
+    cen.resize((size_t)n * 3);
+    for (uint32_t i = 0; i < n; ++i) {
+      order[i] = i;
+      for (int a = 0; a < 3; ++a) cen[3 * i + a] = 0.5f * (prims[i].box.lo[a] + prims[i].box.hi[a]);
+    }
+    nodes.clear();
+    nodes.emplace_back();
+    std::memset(&nodes[0], 0, sizeof(Node));
+    if (n == 0) {
+      set_child(nodes[0], 0, empty_box(), LEAF_BIT);
+      set_child(nodes[0], 1, empty_box(), LEAF_BIT);
+      max_depth = 1;
+      return;
+    }
+    if (leaf_ok(0, n)) {  // whole scene in one leaf: root = {leaf, nothing}
+      set_child(nodes[0], 0, range_box(0, n), leaf_word(0, n));
+      set_child(nodes[0], 1, empty_box(), LEAF_BIT);
+      max_depth = 1;
+      return;
+    }
+    struct Item { uint32_t node, first, count, depth; };
+    std::vector<Item> stack{{0u, 0u, n, 1u}};
+    while (!stack.empty()) {
+      Item it = stack.back();
+      stack.pop_back();
+      max_depth = std::max(max_depth, it.depth);
+      uint32_t mid = split(it.first, it.count);
+      uint32_t cf[2] = {it.first, mid}, cc[2] = {mid - it.first, it.first + it.count - mid};
+      for (int c = 0; c < 2; ++c) {
+        Box b = range_box(cf[c], cc[c]);
+        if (leaf_ok(cf[c], cc[c])) {
+          set_child(nodes[it.node], c, b, leaf_word(cf[c], cc[c]));
+        } else {
+          uint32_t idx = (uint32_t)nodes.size();
+          nodes.emplace_back();
+          std::memset(&nodes.back(), 0, sizeof(Node));
+          set_child(nodes[it.node], c, b, idx);
+          stack.push_back({idx, cf[c], cc[c], it.depth + 1});
+        }
+      }
+    }
+  }
+};
+
+void finish_accel(const std::vector<Prim>& prims, uint32_t max_leaf, BuiltAccel& out,
+                  std::vector<uint32_t>& order) {
+  Builder b(prims, max_leaf);
+  b.build();
+  out.nodes = std::move(b.nodes);
+  out.depth = b.max_depth + 1;
+  out.isect.resize(prims.size());
+  for (size_t s = 0; s < prims.size(); ++s) out.isect[s] = prims[b.order[s]].isect;
+  order = std::move(b.order);
+}
+
+}  // namespace
+
+int pack_scene(const rene_scene_desc* d, PackedScene& out, std::string& err) {
+  if (!d) { err = "scene is NULL"; return RENE_ERR_INVALID_ARGUMENT; }
+  if (d->struct_size != sizeof(rene_scene_desc)) {
+    err = "rene_scene_desc.struct_size mismatch (ABI skew)";
+    return RENE_ERR_INVALID_ARGUMENT;
+  }
+  if (d->integrator != RENE_INTEGRATOR_PATH) {
+    err = "Integrator volpath is not built yet (SURVEY section 8 f1)";
+    return RENE_ERR_UNSUPPORTED;
+  }
+  if (d->xresolution < 2 || d->yresolution < 2) {  // lib.rs:178-179 divides by W-1, H-1
+    err = "film resolution must be at least 2x2";
+    return RENE_ERR_INVALID_SCENE;
+  }
+  if (!d->n_materials || !d->n_area_lights || !d->n_textures) {
+    err = "materials / area_lights / textures need their index-0 sentinels (rene/src/scene.rs:109-116)";
+    return RENE_ERR_INVALID_SCENE;
+  }
+  out = PackedScene();
+  out.width = d->xresolution;
+  out.height = d->yresolution;
+  out.uniform = d->uniform;
+  if (d->uniform.background_texture >= d->n_textures) { err = "background_texture out of range"; return RENE_ERR_INVALID_SCENE; }
+
+  // ---- tables ----
+  out.materials.resize(d->n_materials);
+  for (uint32_t i = 0; i < d->n_materials; ++i) {
+    const rene_material& m = d->materials[i];
+    Material& o = out.materials[i];
+    std::memset(&o, 0, sizeof(o));
+    o.type = m.type;
+    std::memcpy(o.u0, m.u0, 16);
+    std::memcpy(o.u1, m.u1, 16);
+    std::memcpy(o.v0, m.v0, 16);
+    if (m.type > RENE_MATERIAL_PLASTIC) { err = "unknown material type"; return RENE_ERR_INVALID_SCENE; }
+    // texture indices that the material will dereference
+    uint32_t refs[7];
+    int nrefs = 0;
+    switch (m.type) {
+      case RENE_MATERIAL_MATTE: case RENE_MATERIAL_MIRROR: refs[nrefs++] = m.u0[0]; break;
+      case RENE_MATERIAL_SUBSTRATE: case RENE_MATERIAL_METAL:
+        for (int k = 0; k < 4; ++k) refs[nrefs++] = m.u0[k];
+        break;
+      case RENE_MATERIAL_UBER:
+        for (int k = 0; k < 4; ++k) refs[nrefs++] = m.u0[k];
+        refs[nrefs++] = m.u1[0]; refs[nrefs++] = m.u1[2]; refs[nrefs++] = m.u1[3];
+        break;
+      case RENE_MATERIAL_PLASTIC: refs[nrefs++] = m.u0[0]; refs[nrefs++] = m.u0[1]; refs[nrefs++] = m.u0[3]; break;
+      default: break;
+    }
+    for (int k = 0; k < nrefs; ++k)
+      if (refs[k] >= d->n_textures) { err = "material references a texture out of range"; return RENE_ERR_INVALID_SCENE; }
+    if (m.type != RENE_MATERIAL_NONE && m.type != RENE_MATERIAL_MATTE) out.features |= FEAT_GENERAL_BSDF;
+    if (m.type == RENE_MATERIAL_UBER || m.type == RENE_MATERIAL_PLASTIC) out.features |= FEAT_MULTI_LOBE;
+  }
+  out.textures.resize(d->n_textures);
+  for (uint32_t i = 0; i < d->n_textures; ++i) {
+    const rene_texture& t = d->textures[i];
+    Texture& o = out.textures[i];
+    std::memset(&o, 0, sizeof(o));
+    o.type = t.type;
+    std::memcpy(o.u0, t.u0, 16);
+    std::memcpy(o.v0, t.v0, 16);
+    if (t.type > RENE_TEXTURE_SCALE) { err = "unknown texture type"; return RENE_ERR_INVALID_SCENE; }
+    if (t.type != RENE_TEXTURE_SOLID) out.features |= FEAT_TEXTURES;
+    if ((t.type == RENE_TEXTURE_CHECKERBOARD || t.type == RENE_TEXTURE_SCALE) &&
+        (t.u0[0] >= d->n_textures || t.u0[1] >= d->n_textures)) {
+      err = "texture references a texture out of range";
+      return RENE_ERR_INVALID_SCENE;
+    }
+    if (t.type == RENE_TEXTURE_IMAGEMAP && t.u0[0] >= d->n_images) { err = "imagemap references an image out of range"; return RENE_ERR_INVALID_SCENE; }
+  }
+  for (uint32_t i = 0; i < d->n_images; ++i) {
+    const rene_image& im = d->images[i];
+    if (!im.rgba || !im.width || !im.height) { err = "empty image"; return RENE_ERR_INVALID_SCENE; }
+    ImageRef r{(uint64_t)out.image_pool.size(), im.width, im.height};
+    out.image_pool.insert(out.image_pool.end(), im.rgba, im.rgba + (size_t)4 * im.width * im.height);
+    out.images.push_back(r);
+  }
+  for (uint32_t i = 0; i < d->n_lights; ++i) {
+    if (d->lights[i].type != RENE_LIGHT_DISTANT) { err = "unknown light type"; return RENE_ERR_INVALID_SCENE; }
+    Light l;
+    std::memcpy(l.dir, d->lights[i].v0, 16);
+    std::memcpy(l.L, d->lights[i].v1, 16);
+    out.lights.push_back(l);
+  }
+  if (d->n_lights) out.features |= FEAT_LIGHTS;
+  if (d->uniform.background_color[0] != 0.f || d->uniform.background_color[1] != 0.f ||
+      d->uniform.background_color[2] != 0.f)
+    out.features |= FEAT_BACKGROUND;
+
+  // ---- flatten instances to world space ----
+  std::vector<Prim> prims, eprims;
+  for (uint32_t ii = 0; ii < d->n_instances; ++ii) {
+    const rene_instance& in = d->instances[ii];
+    if (in.material_index >= d->n_materials || in.area_light_index >= d->n_area_lights) {
+      err = "instance references a material / area light out of range";
+      return RENE_ERR_INVALID_SCENE;
+    }
+    for (int k = 0; k < 12; ++k)
+      if (!std::isfinite(in.matrix[k])) { err = "non-finite instance matrix"; return RENE_ERR_INVALID_SCENE; }
+    Aff o2w = aff_from(in.matrix), w2o;
+    if (!aff_inverse(o2w, w2o)) { err = "singular instance matrix"; return RENE_ERR_INVALID_SCENE; }
+    const rene_material& mat = d->materials[in.material_index];
+    const rene_area_light& al = d->area_lights[in.area_light_index];
+    bool emitter = al.type != RENE_AREA_LIGHT_NULL;
+    Inst inst;
+    std::memset(&inst, 0, sizeof(inst));
+    inst.material = in.material_index;
+    inst.area_light = in.area_light_index;
+    inst.material_type = mat.type;
+    if (mat.type == RENE_MATERIAL_MATTE && d->textures[mat.u0[0]].type == RENE_TEXTURE_SOLID) {
+      const float* c = d->textures[mat.u0[0]].v0;
+      inst.kd[0] = c[0]; inst.kd[1] = c[1]; inst.kd[2] = c[2]; inst.kd[3] = 1.0f;
+    }
+    if (emitter) { inst.emit[0] = al.v0[0]; inst.emit[1] = al.v0[1]; inst.emit[2] = al.v0[2]; inst.emit[3] = 1.0f; }
+
+    if (in.shape == RENE_SHAPE_SPHERE) {
+      out.features |= FEAT_SPHERES;
+      inst.primitive_count = 1.0f;  // main.rs:3071-3074
+      Sphere s;
+      std::memcpy(s.o2w, in.matrix, 48);
+      const float w[12] = {w2o.x.x, w2o.x.y, w2o.x.z, w2o.y.x, w2o.y.y, w2o.y.z,
+                           w2o.z.x, w2o.z.y, w2o.z.z, w2o.w.x, w2o.w.y, w2o.w.z};
+      std::memcpy(s.w2o, w, 48);
+      uint32_t sidx = (uint32_t)out.spheres.size();
+      out.spheres.push_back(s);
+      Prim p;
+      std::memset(&p, 0, sizeof(p));
+      p.sphere = true;
+      p.box.reset();
+      for (int c = 0; c < 8; ++c)  // unit AABB BLAS, main.rs:2444-2451
+        p.box.grow(xform_point(o2w, V3{c & 1 ? 1.f : -1.f, c & 2 ? 1.f : -1.f, c & 4 ? 1.f : -1.f}));
+      pad_box(p.box);
+      p.isect.q[9] = bits_to_float(ii);
+      p.isect.q[10] = bits_to_float(0u);
+      p.isect.q[11] = bits_to_float(sidx);
+      prims.push_back(p);
+      if (emitter) {
+        eprims.push_back(p);
+        EmitObject eo;
+        std::memset(&eo, 0, sizeof(eo));
+        eo.type = 1;
+        eo.prim_count = 1;
+        std::memcpy(eo.matrix, in.matrix, 48);
+        out.emit_objects.push_back(eo);
+      }
+    } else if (in.shape == RENE_SHAPE_TRIANGLE) {
+      if (in.mesh_index < 0 || (uint32_t)in.mesh_index >= d->n_meshes) { err = "instance mesh_index out of range"; return RENE_ERR_INVALID_SCENE; }
+      const rene_mesh& me = d->meshes[in.mesh_index];
+      if (me.n_indices % 3) { err = "mesh index count is not a multiple of 3"; return RENE_ERR_INVALID_SCENE; }
+      uint32_t ntri = me.n_indices / 3;
+      inst.primitive_count = (float)ntri;
+      EmitObject eo;
+      if (emitter) {
+        std::memset(&eo, 0, sizeof(eo));
+        eo.type = 0;
+        eo.first_tri = (uint32_t)out.emit_tris.size();
+        eo.prim_count = ntri;
+        std::memcpy(eo.matrix, in.matrix, 48);
+        if (ntri == 0) { err = "emitter mesh without triangles"; return RENE_ERR_INVALID_SCENE; }  // `% 0`, surface_sample.rs:75
+        out.emit_objects.push_back(eo);
+      }
+      for (uint32_t t = 0; t < ntri; ++t) {
+        const rene_vertex* v[3];
+        for (int k = 0; k < 3; ++k) {
+          uint32_t idx = me.indices[3 * t + k];
+          if (idx >= me.n_vertices) { err = "mesh index out of range"; return RENE_ERR_INVALID_SCENE; }
+          v[k] = &me.vertices[idx];
+        }
+        V3 po[3], pw[3], nw[3];
+        bool all_zero = true;
+        for (int k = 0; k < 3; ++k) {
+          po[k] = V3{v[k]->position[0], v[k]->position[1], v[k]->position[2]};
+          pw[k] = xform_point(o2w, po[k]);
+          if (v[k]->normal[0] != 0.f || v[k]->normal[1] != 0.f || v[k]->normal[2] != 0.f) all_zero = false;
+        }
+        V3 ng_obj = cross(sub(po[1], po[0]), sub(po[2], po[0]));
+        V3 ng_w = xform_normal(w2o, ng_obj);
+        for (int k = 0; k < 3; ++k)
+          nw[k] = all_zero ? ng_w : xform_normal(w2o, V3{v[k]->normal[0], v[k]->normal[1], v[k]->normal[2]});
+        Prim p;
+        std::memset(&p, 0, sizeof(p));
+        p.sphere = false;
+        p.box.reset();
+        for (int k = 0; k < 3; ++k) p.box.grow(pw[k]);
+        pad_box(p.box);
+        V3 e1 = sub(pw[1], pw[0]), e2 = sub(pw[2], pw[0]);
+        float* q = p.isect.q;
+        q[0] = pw[0].x; q[1] = pw[0].y; q[2] = pw[0].z; q[3] = e1.x; q[4] = e1.y; q[5] = e1.z;
+        q[6] = e2.x; q[7] = e2.y; q[8] = e2.z;
+        q[9] = bits_to_float(ii); q[10] = bits_to_float(t); q[11] = bits_to_float(0xffffffffu);
+        float* s = p.shade.q;
+        s[0] = nw[0].x; s[1] = nw[0].y; s[2] = nw[0].z; s[3] = v[0]->uv[0];
+        s[4] = nw[1].x; s[5] = nw[1].y; s[6] = nw[1].z; s[7] = v[0]->uv[1];
+        s[8] = nw[2].x; s[9] = nw[2].y; s[10] = nw[2].z; s[11] = v[1]->uv[0];
+        s[12] = v[1]->uv[1]; s[13] = v[2]->uv[0]; s[14] = v[2]->uv[1]; s[15] = 0.f;
+        prims.push_back(p);
+        if (emitter) {
+          // triangle_closest_hit_pdf operands, lib.rs:1004-1036
+          float len = std::sqrt(dot(ng_w, ng_w));
+          V3 c = cross(e1, e2);
+          p.pdf.q[0] = ng_w.x / len; p.pdf.q[1] = ng_w.y / len; p.pdf.q[2] = ng_w.z / len;
+          p.pdf.q[3] = 0.5f * std::sqrt(dot(c, c));
+          eprims.push_back(p);
+          EmitTri et;
+          std::memset(&et, 0, sizeof(et));
+          et.q[0] = pw[0].x; et.q[1] = pw[0].y; et.q[2] = pw[0].z; et.q[3] = pw[1].x; et.q[4] = pw[1].y;
+          et.q[5] = pw[1].z; et.q[6] = pw[2].x; et.q[7] = pw[2].y; et.q[8] = pw[2].z;
+          out.emit_tris.push_back(et);
+        }
+      }
+      out.n_triangles += ntri;
+    } else {
+      err = "unknown instance shape";
+      return RENE_ERR_INVALID_SCENE;
+    }
+    out.insts.push_back(inst);
+  }
+  if (prims.size() > LEAF_FIRST_MASK) { err = "too many primitives for the 26-bit leaf index"; return RENE_ERR_UNSUPPORTED; }
+
+  std::vector<uint32_t> order;
+  finish_accel(prims, 4, out.main, order);
+  out.shade.resize(prims.size());
+  for (size_t s = 0; s < prims.size(); ++s) out.shade[s] = prims[order[s]].shade;
+  finish_accel(eprims, 4, out.emit, order);
+  out.emit_pdf.resize(eprims.size());
+  for (size_t s = 0; s < eprims.size(); ++s) out.emit_pdf[s] = eprims[order[s]].pdf;
+  return RENE_OK;
+}
+
+}  // namespace rene

@@ -1,0 +1,41 @@
+// scene_pack.h -- host side of the upload step: flatten rene's Scene tables into the HBM layout of
+// device_scene.h and build the two BVHs.  Replaces SceneBuffers::new (rene/src/main.rs:2910-3336)
+// and the driver's acceleration-structure builds (main.rs:2437-2908).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../include/rene_hip.h"
+#include "device_scene.h"
+
+namespace rene {
+
+struct BuiltAccel {
+  std::vector<Node> nodes;
+  std::vector<PrimIsect> isect;  // slot order
+  uint32_t depth = 0;            // max stack depth a traversal can need
+};
+
+struct PackedScene {
+  BuiltAccel main, emit;
+  std::vector<PrimShade> shade;   // main slot order
+  std::vector<EmitPdf> emit_pdf;  // emit slot order
+  std::vector<Sphere> spheres;
+  std::vector<Inst> insts;
+  std::vector<EmitObject> emit_objects;
+  std::vector<EmitTri> emit_tris;
+  std::vector<Material> materials;
+  std::vector<Texture> textures;
+  std::vector<Light> lights;
+  std::vector<ImageRef> images;
+  std::vector<float> image_pool;
+  rene_uniform uniform{};
+  uint32_t width = 0, height = 0;
+  uint32_t features = 0;
+  uint32_t n_triangles = 0;  // world-space triangles after flattening
+};
+
+// returns a rene_status; fills err on failure
+int pack_scene(const rene_scene_desc* d, PackedScene& out, std::string& err);
+
+}  // namespace rene
