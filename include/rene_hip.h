@@ -219,6 +219,20 @@ typedef struct rene_hit {
   uint32_t primitive;
 } rene_hit;
 
+/* What rene_create would build for a scene; filled by rene_scene_pack_info without touching the
+ * GPU (host-side validation + flattening + BVH build only). */
+typedef struct rene_pack_info {
+  uint32_t n_instances;
+  uint32_t n_triangles;      /* world-space triangles after instancing is flattened */
+  uint32_t n_spheres;
+  uint32_t n_nodes_main, n_slots_main, depth_main;
+  uint32_t n_nodes_emit, n_slots_emit, depth_emit;
+  uint32_t features;         /* kernel specialisation bits */
+  uint32_t emit_object_len;  /* rene/src/main.rs:3279 */
+  uint32_t lights_len;       /* rene/src/scene.rs:166 */
+  uint64_t device_bytes;     /* HBM the scene tables will occupy (framebuffer excluded) */
+} rene_pack_info;
+
 typedef struct rene_ctx rene_ctx;
 
 /* ---- render path ----------------------------------------------------------------------------- */
@@ -253,6 +267,10 @@ int rene_trace(rene_ctx* ctx, int which, size_t n, const float* origins, const f
                float tmin, float tmax, rene_hit* out);
 
 void rene_destroy(rene_ctx* ctx);
+
+/* Validate + flatten + build on the host only (no HIP call): same checks and status codes as
+ * rene_create. */
+int rene_scene_pack_info(const rene_scene_desc* scene, rene_pack_info* out);
 
 const char* rene_last_error(void);
 uint32_t rene_abi_version(void);

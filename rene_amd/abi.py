@@ -107,6 +107,17 @@ class Stats(C.Structure):
         return d
 
 
+class PackInfo(C.Structure):
+    _fields_ = [("n_instances", u32), ("n_triangles", u32), ("n_spheres", u32),
+                ("n_nodes_main", u32), ("n_slots_main", u32), ("depth_main", u32),
+                ("n_nodes_emit", u32), ("n_slots_emit", u32), ("depth_emit", u32),
+                ("features", u32), ("emit_object_len", u32), ("lights_len", u32),
+                ("device_bytes", u64)]
+
+    def as_dict(self) -> dict:
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
 class Hit(C.Structure):
     _fields_ = [("t", f32), ("u", f32), ("v", f32), ("instance", u32), ("primitive", u32)]
 
@@ -123,7 +134,7 @@ def algorithmic_bytes(stats) -> int:
 # every symbol include/rene_hip.h declares (tests check that the shared library exports them all)
 EXPORTED_SYMBOLS = [
     "rene_create", "rene_render", "rene_sync", "rene_download", "rene_reset", "rene_framebuffer",
-    "rene_get_stats", "rene_trace", "rene_destroy", "rene_last_error", "rene_abi_version",
+    "rene_get_stats", "rene_trace", "rene_destroy", "rene_scene_pack_info", "rene_last_error", "rene_abi_version",
     "rene_to_rgb8", "rene_to_aov8", "rene_frame_seeds",
     "rene_scene_load_pbrt", "rene_scene_parse_pbrt", "rene_scene_get_desc",
     "rene_scene_film_filename", "rene_scene_free",

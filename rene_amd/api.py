@@ -52,6 +52,7 @@ def lib():
     L.rene_get_stats.argtypes = [vp, C.POINTER(abi.Stats)]
     L.rene_trace.argtypes = [vp, i32, C.c_size_t, vp, vp, C.c_float, C.c_float, vp]
     L.rene_destroy.argtypes = [vp]
+    L.rene_scene_pack_info.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(abi.PackInfo)]
     L.rene_destroy.restype = None
     L.rene_last_error.restype = C.c_char_p
     L.rene_abi_version.restype = u32
@@ -153,6 +154,14 @@ class Renderer:
         _check(lib().rene_trace(self._h, which, o.shape[0], o.ctypes.data_as(C.c_void_p),
                                 d.ctypes.data_as(C.c_void_p), tmin, tmax, out.ctypes.data_as(C.c_void_p)))
         return out
+
+
+def pack_info(scene) -> abi.PackInfo:
+    """Host-only validation + flattening + BVH build (no GPU needed)."""
+    packed = scene if hasattr(scene, "byref") else scene.to_desc()
+    info = abi.PackInfo()
+    _check(lib().rene_scene_pack_info(packed.byref(), C.byref(info)))
+    return info
 
 
 def to_rgb8(sums: np.ndarray, n_samples: int) -> np.ndarray:

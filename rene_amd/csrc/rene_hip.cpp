@@ -118,6 +118,35 @@ void rene_frame_seeds(uint32_t master_seed, uint32_t first_frame, uint32_t n, ui
   for (uint32_t k = 0; k < n; ++k) out[k] = g.next();
 }
 
+int rene_scene_pack_info(const rene_scene_desc* scene, rene_pack_info* out) {
+  if (!scene || !out) return fail(RENE_ERR_INVALID_ARGUMENT, "rene_scene_pack_info: NULL argument");
+  rene::PackedScene ps;
+  std::string err;
+  int rc = rene::pack_scene(scene, ps, err);
+  if (rc != RENE_OK) return fail(rc, err);
+  std::memset(out, 0, sizeof(*out));
+  out->n_instances = (uint32_t)ps.insts.size();
+  out->n_triangles = ps.n_triangles;
+  out->n_spheres = (uint32_t)ps.spheres.size();
+  out->n_nodes_main = (uint32_t)ps.main.nodes.size();
+  out->n_slots_main = (uint32_t)ps.main.isect.size();
+  out->depth_main = ps.main.depth;
+  out->n_nodes_emit = (uint32_t)ps.emit.nodes.size();
+  out->n_slots_emit = (uint32_t)ps.emit.isect.size();
+  out->depth_emit = ps.emit.depth;
+  out->features = ps.features;
+  out->emit_object_len = (uint32_t)ps.emit_objects.size();
+  out->lights_len = (uint32_t)ps.lights.size();
+  out->device_bytes = ps.main.nodes.size() * sizeof(rene::Node) + ps.main.isect.size() * sizeof(rene::PrimIsect) +
+                      ps.emit.nodes.size() * sizeof(rene::Node) + ps.emit.isect.size() * sizeof(rene::PrimIsect) +
+                      ps.shade.size() * sizeof(rene::PrimShade) + ps.emit_pdf.size() * sizeof(rene::EmitPdf) +
+                      ps.spheres.size() * sizeof(rene::Sphere) + ps.insts.size() * sizeof(rene::Inst) +
+                      ps.emit_objects.size() * sizeof(rene::EmitObject) + ps.emit_tris.size() * sizeof(rene::EmitTri) +
+                      ps.materials.size() * sizeof(rene::Material) + ps.textures.size() * sizeof(rene::Texture) +
+                      ps.lights.size() * sizeof(rene::Light) + ps.image_pool.size() * sizeof(float);
+  return RENE_OK;
+}
+
 int rene_create(const rene_scene_desc* scene, const rene_opts* opts, rene_ctx** out) {
   if (!scene || !out) return fail(RENE_ERR_INVALID_ARGUMENT, "rene_create: NULL argument");
   *out = nullptr;

@@ -1,0 +1,69 @@
+"""Regenerates the committed fixtures under tests/golden/.
+
+Nothing here reads the reference at run time: the PCG32si known answers come from an independent
+pure-Python restatement of rene-shader/src/rand.rs:4-52 (also quoted in SURVEY.md section 8a A2);
+the render fixtures come from the CPU oracle (oracle/rene_oracle.cpp) and pin it against silent
+regressions -- they are NOT reference-produced outputs (the reference cannot run here, see
+DESIGN.md "Oracle").
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+M32 = 0xFFFFFFFF
+
+
+class PyPcg:  # rand.rs:4-52, integer arithmetic only
+    def __init__(self, seed):
+        self.s = seed & M32
+        self._step()
+        self.s = (self.s + seed) & M32
+        self._step()
+
+    def _step(self):
+        self.s = (self.s * 747796405 + 2891336453) & M32
+
+    def next_u32(self):
+        o = self.s
+        self._step()
+        w = (((o >> ((o >> 28) + 4)) ^ o) * 277803737) & M32
+        return ((w >> 22) ^ w) & M32
+
+
+def main():
+    kat = {}
+    for seed in (0, 1, 42, 0xDEADBEEF, 0x52454E45, 0xFFFFFFFF):
+        g = PyPcg(seed)
+        state = g.s
+        vals = [g.next_u32() for _ in range(8)]
+        kat[str(seed)] = {"state_after_new": state, "u32": vals,
+                          "f32_bits_num": [v >> 8 for v in vals]}  # next_f32 = (v >> 8) * 2^-24
+    with open(os.path.join(HERE, "pcg32si_kat.json"), "w") as f:
+        json.dump(kat, f, indent=1)
+
+    from rene_amd import scenes
+    from oracle import oracle
+    s = scenes.cornell_box(64, 64)
+    o = oracle.Oracle(s)
+    o.render(0, 4, threads=1)
+    np.save(os.path.join(HERE, "cornell_64x64_4spp_layers.npy"),
+            np.stack([o.download(l) for l in range(3)]).astype(np.float32))
+    st = o.stats().as_dict()
+    with open(os.path.join(HERE, "cornell_64x64_4spp_stats.json"), "w") as f:
+        json.dump({k: st[k] for k in ("rays_closest", "rays_emitter", "rays_shadow", "paths", "hits", "adds")}, f)
+    rays = {"s": [0.0, 1.0, 0.5, 0.25], "t": [0.0, 1.0, 0.5, 0.75], "o": [], "d": []}
+    for a, b in zip(rays["s"], rays["t"]):
+        ro, rd = o.camera_ray(a, b)
+        rays["o"].append([float(x) for x in ro])
+        rays["d"].append([float(x) for x in rd])
+    with open(os.path.join(HERE, "cornell_camera_rays.json"), "w") as f:
+        json.dump(rays, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,155 @@
+"""The C-ABI library loads on a machine without a GPU, exports every symbol the header declares,
+its structs have the sizes the ctypes mirror assumes, and its host-only entry points behave."""
+import ctypes as C
+import os
+import re
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from rene_amd import abi, api, scenes
+from rene_amd.scene import Scene, TriangleMesh
+from rene_amd import glam
+
+HEADER = os.path.join(ROOT, "include", "rene_hip.h")
+
+
+def test_header_is_plain_c_and_sizes_match_ctypes():
+    names = {"rene_vertex": abi.Vertex, "rene_mesh": abi.Mesh, "rene_instance": abi.Instance,
+             "rene_material": abi.Material, "rene_texture": abi.Texture, "rene_area_light": abi.AreaLight,
+             "rene_light": abi.Light, "rene_image": abi.Image, "rene_uniform": abi.Uniform,
+             "rene_scene_desc": abi.SceneDesc, "rene_opts": abi.Opts, "rene_stats": abi.Stats,
+             "rene_hit": abi.Hit, "rene_pack_info": abi.PackInfo}
+    prog = '#include <stdio.h>\n#include "rene_hip.h"\nint main(void){\n'
+    for n in names:
+        prog += f'printf("{n} %zu\\n", sizeof({n}));\n'
+    prog += 'printf("offset_instances %zu\\n", offsetof(rene_scene_desc, instances));\n'
+    prog += 'printf("offset_framebuffer %zu\\n", offsetof(rene_opts, framebuffer));\nreturn 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "t.c")
+        open(src, "w").write(prog)
+        exe = os.path.join(d, "t")
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.dirname(HEADER), src, "-o", exe])
+        out = dict(l.split() for l in subprocess.check_output([exe]).decode().splitlines())
+    for n, cls in names.items():
+        assert int(out[n]) == C.sizeof(cls), n
+    assert int(out["offset_instances"]) == abi.SceneDesc.instances.offset
+    assert int(out["offset_framebuffer"]) == abi.Opts.framebuffer.offset
+
+
+def test_library_exports_every_declared_symbol(hip_lib):
+    text = open(HEADER).read()
+    declared = set(re.findall(r"\b(rene_[a-z0-9_]+)\s*\(", text))
+    declared -= {"rene_status"}
+    assert declared == set(abi.EXPORTED_SYMBOLS), declared ^ set(abi.EXPORTED_SYMBOLS)
+    for name in declared:
+        assert hasattr(hip_lib, name), name
+    assert hip_lib.rene_abi_version() == abi.ABI_VERSION
+
+
+def test_no_oracle_in_product(hip_lib):
+    """The product must not link, import or call anything under oracle/."""
+    out = subprocess.check_output(["ldd", api.LIB_PATH]).decode()
+    assert "oracle" not in out
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "rene_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip")) or f == "Makefile":
+                t = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "import oracle" not in t and "from oracle" not in t and "oracle/" not in t.replace(
+                    "under oracle/", "").replace("oracle/ is", ""), f
+
+
+def test_frame_seeds_follow_pcg_schedule(hip_lib, oracle_mod):
+    got = api.frame_seeds(abi.DEFAULT_SEED, 0, 8)
+    assert got.tolist() == oracle_mod.pcg_u32(abi.DEFAULT_SEED, 8).tolist()
+    assert api.frame_seeds(7, 5, 3).tolist() == oracle_mod.pcg_u32(7, 8)[5:].tolist()
+
+
+def test_output_transform_matches_restatement(hip_lib, oracle_mod):
+    rng = np.random.default_rng(3)
+    v = np.concatenate([rng.uniform(0, 2, 4000), rng.uniform(0, 0.004, 500),
+                        [0.0, -1.0, 1.0, 0.0031308, np.nan, np.inf, 1e-9, 0.5 / 255 / 12.92 * 16]]).astype(np.float32)
+    sums = (v * np.float32(16)).astype(np.float32)
+    got = api.to_rgb8(sums, 16)
+    want = oracle_mod.to_rgb8(sums, 16)
+    # powf may differ by an ulp between libm and numpy: allow off-by-one on a handful of values
+    d = np.abs(got.astype(int) - want.astype(int))
+    assert d.max() <= 1 and (d > 0).mean() < 2e-3
+    assert got[-4] == 0 and got[-3] == 255  # NaN -> 0 (Rust `as u8`), inf -> 255
+    aov = api.to_aov8(np.array([0.0, 8.0, 16.0, -16.0], np.float32), 16, False)
+    assert aov.tolist() == [0, 128, 255, 0]  # (256 * clamp(v, 0, 0.999)) as u8, main.rs:1794-1801
+    aovn = api.to_aov8(np.array([0.0, 16.0, -16.0], np.float32), 16, True)
+    assert aovn.tolist() == [128, 255, 0]
+
+
+def test_pack_info_cornell(hip_lib):
+    info = api.pack_info(scenes.cornell_box(64, 64)).as_dict()
+    assert info["n_triangles"] == 36 and info["n_instances"] == 8 and info["n_spheres"] == 0
+    assert info["emit_object_len"] == 1 and info["lights_len"] == 0 and info["n_slots_emit"] == 2
+    assert info["features"] == 0  # Matte-only fast path
+    assert info["n_slots_main"] == 36 and 1 <= info["n_nodes_main"] < 36
+
+
+def _tiny(**kw):
+    s = Scene.new()
+    s.set_camera(glam.identity(), 45.0, kw.get("w", 16), kw.get("h", 16))
+    return s
+
+
+def test_validation_errors(hip_lib):
+    def code(scene_or_packed):
+        with pytest.raises(api.ReneError) as e:
+            api.pack_info(scene_or_packed)
+        return e.value.code
+
+    s = _tiny()
+    s.add_triangle_mesh(TriangleMesh.from_arrays([0, 0, 0, 1, 0, 0, 0, 1, 0], [0, 1, 2]), material=99)
+    assert code(s) == -2  # material out of range
+    s = _tiny()
+    s.integrator = abi.INTEGRATOR_VOLPATH
+    assert code(s) == -4  # volpath: unsupported, not silently rendered as path
+    s = _tiny(w=1, h=16)
+    assert code(s) == -2  # W-1 division, lib.rs:178
+    s = _tiny()
+    p = s.to_desc()
+    p.desc.struct_size = 12
+    assert code(p) == -1  # ABI skew
+    s = _tiny()
+    m = TriangleMesh.from_arrays([0, 0, 0, 1, 0, 0, 0, 1, 0], [0, 1, 2])
+    s.add_triangle_mesh(m, s.add_matte())
+    s.instances[0].matrix[:] = [0.0] * 12
+    assert code(s) == -2  # singular instance matrix
+    s = _tiny()
+    s.add_triangle_mesh(m, s.add_matte())
+    s.instances[0].mesh_index = 5
+    assert code(s) == -2
+    # empty scene is valid (every ray misses)
+    assert api.pack_info(_tiny()).n_slots_main == 0
+
+
+def test_pack_info_features(hip_lib):
+    s = _tiny()
+    s.add_sphere(0.5, s.add_metal(rough_u=0.1, rough_v=0.1, remap_roughness=False),
+                 area_light=s.add_area_light_diffuse((1, 1, 1)))
+    s.add_light_distant((0, 0, 1), (0, 0, 0), (1, 1, 1))
+    info = api.pack_info(s).as_dict()
+    assert info["n_spheres"] == 1 and info["emit_object_len"] == 1 and info["lights_len"] == 1
+    assert info["features"] & 1 and info["features"] & 2 and info["features"] & 8
+    # instancing is flattened: two instances of one mesh -> twice the triangles
+    s = _tiny()
+    m = TriangleMesh.from_arrays([0, 0, 0, 1, 0, 0, 0, 1, 0, 1, 1, 0], [0, 1, 2, 1, 3, 2])
+    i0 = s.add_triangle_mesh(m, s.add_matte())
+    s.add_mesh_instance(0, 1, ctm=glam.from_translation((3, 0, 0)))
+    assert api.pack_info(s).n_triangles == 4
+
+
+def test_render_path_fails_loudly_without_gpu(hip_lib):
+    from conftest import has_gpu
+    if has_gpu():
+        pytest.skip("GPU present")
+    with pytest.raises(api.ReneError) as e:
+        api.Renderer(scenes.cornell_box(16, 16))
+    assert e.value.code == -3  # RENE_ERR_DEVICE: no CPU fallback

@@ -1,0 +1,70 @@
+"""world_size-2 `gloo` rehearsal of the multi-GPU path on CPU: tile sharding + the one framebuffer
+reduce.  The per-rank images come from the oracle here (the product path
+needs a GPU); what is exercised is rene_amd.dist and the shard definition it shares with the
+kernel."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    from rene_amd import abi, dist as rdist, scenes
+    from oracle import oracle
+    rdist.init_process_group("gloo")
+    o = oracle.Oracle(scenes.cornell_box(96, 80))
+    o.render(0, 3, threads=1, shard_mode=abi.SHARD_TILES, shard_rank=rank, shard_count=world)
+    fb = torch.from_numpy(np.stack([o.download(l, 4) for l in range(3)]))
+    rdist.reduce_framebuffer(fb, dst=0)
+    dist.barrier()
+    if rank == 0:
+        q.put(fb.numpy())
+    dist.destroy_process_group()
+
+
+def test_two_rank_tile_shard_reduce_equals_single():
+    import torch.multiprocessing as mp
+    from rene_amd import scenes
+    from oracle import oracle
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    o = oracle.Oracle(scenes.cornell_box(96, 80))
+    o.render(0, 3, threads=1)
+    want = np.stack([o.download(l, 4) for l in range(3)])
+    assert np.array_equal(got, want)  # each pixel has one owner: the reduce adds exact zeros
+
+
+def test_tile_owner_map_partitions_image():
+    from rene_amd.dist import tile_owner_map
+    for w, h, n in ((96, 80, 3), (1024, 1024, 8), (33, 31, 2), (1920, 1080, 8)):
+        own = tile_owner_map(w, h, n)
+        assert own.shape == (h, w) and own.min() == 0 and own.max() == min(n, ((w + 31) // 32) * ((h + 31) // 32)) - 1
+        counts = np.bincount(own.ravel(), minlength=n)
+        assert counts.sum() == w * h
+        if w * h >= 1024 * 1024:
+            assert counts.max() / counts.min() < 1.15  # interleaved tiles balance the pixel load
