@@ -266,6 +266,15 @@ int rene_get_stats(rene_ctx* ctx, rene_stats* out);
 int rene_trace(rene_ctx* ctx, int which, size_t n, const float* origins, const float* directions,
                float tmin, float tmax, rene_hit* out);
 
+/* Per-function probe of the device BSDF code (EnumMaterial::compute_bsdf + Bsdf::{f, pdf, sample_f},
+ * rene-shader/src/material.rs:739-769, reflection.rs:286-342): for each of the n items builds the
+ * lobes of `material_index` at (normal, uv) and writes 12 floats: f(wo,wi).rgb, pdf(wo,wi),
+ * sample.wi.xyz, sample.f.rgb, sample.pdf (one sample_f(wo) from PCG32si::new(seed)), lobe count.
+ * Host pointers; world-space directions. */
+int rene_bsdf_eval(rene_ctx* ctx, uint32_t material_index, size_t n, const float* normals3,
+                   const float* uvs2, const float* wo3, const float* wi3, const uint32_t* seeds,
+                   float* out12);
+
 void rene_destroy(rene_ctx* ctx);
 
 /* Validate + flatten + build on the host only (no HIP call): same checks and status codes as

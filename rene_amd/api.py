@@ -41,6 +41,13 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise ReneError(-3, f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                             "(there is no CPU fallback for the render path)")
+    # PyTorch bundles its own libamdhip64.so.7; whichever copy is loaded first serves the whole
+    # process.  Load torch's first (when torch is installed) so that device pointers and streams can
+    # be shared with torch tensors / torch.distributed (bench.py, multi-GPU reduce).
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int
     L.rene_create.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(abi.Opts), C.POINTER(vp)]
@@ -51,6 +58,7 @@ def lib():
     L.rene_framebuffer.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.rene_get_stats.argtypes = [vp, C.POINTER(abi.Stats)]
     L.rene_trace.argtypes = [vp, i32, C.c_size_t, vp, vp, C.c_float, C.c_float, vp]
+    L.rene_bsdf_eval.argtypes = [vp, u32, C.c_size_t, vp, vp, vp, vp, vp, vp]
     L.rene_destroy.argtypes = [vp]
     L.rene_scene_pack_info.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(abi.PackInfo)]
     L.rene_destroy.restype = None
@@ -154,6 +162,20 @@ class Renderer:
         _check(lib().rene_trace(self._h, which, o.shape[0], o.ctypes.data_as(C.c_void_p),
                                 d.ctypes.data_as(C.c_void_p), tmin, tmax, out.ctypes.data_as(C.c_void_p)))
         return out
+
+
+def _bsdf_eval(self, material_index: int, normals, uvs, wo, wi, seeds) -> np.ndarray:
+    """Device BSDF probe: returns (n, 12) = f.rgb, pdf, s_wi.xyz, s_f.rgb, s_pdf, lobe count."""
+    a = [np.ascontiguousarray(v, dtype=np.float32) for v in (normals, uvs, wo, wi)]
+    sd = np.ascontiguousarray(seeds, dtype=np.uint32)
+    n = sd.size
+    out = np.zeros((n, 12), np.float32)
+    p = lambda x: x.ctypes.data_as(C.c_void_p)
+    _check(lib().rene_bsdf_eval(self._h, material_index, n, p(a[0]), p(a[1]), p(a[2]), p(a[3]), p(sd), p(out)))
+    return out
+
+
+Renderer.bsdf_eval = _bsdf_eval
 
 
 def pack_info(scene) -> abi.PackInfo:

@@ -1149,6 +1149,47 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(SceneView S, int which, ui
   out[i] = r;
 }
 
+// -------------------------------------------------------------------------------------------------
+// per-function BSDF probe (rene_bsdf_eval): builds the material's lobes at (normal, uv) exactly like
+// the integrator does and returns f(wo,wi), pdf(wo,wi) and one sample_f(wo) drawn from
+// PCG32si::new(seed).  out[12] = f.xyz, pdf, s.wi.xyz, s.f.xyz, s.pdf, len
+// -------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) bsdf_eval_kernel(SceneView S, uint32_t material, uint32_t n, const float* nrm3,
+                                                       const float* uv2_, const float* wo3, const float* wi3,
+                                                       const uint32_t* seeds, float* out) {
+  constexpr uint32_t ALL = FEAT_SPHERES | FEAT_GENERAL_BSDF | FEAT_TEXTURES | FEAT_LIGHTS | FEAT_BACKGROUND | FEAT_MULTI_LOBE;
+  uint32_t i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  Inst inst;
+  inst.material = material;
+  inst.area_light = 0;
+  inst.primitive_count = 1.0f;
+  inst.material_type = S.materials[material].type;
+  inst.kd[0] = inst.kd[1] = inst.kd[2] = inst.kd[3] = 0.0f;
+  inst.emit[0] = inst.emit[1] = inst.emit[2] = inst.emit[3] = 0.0f;
+  f3 normal = normalize(mk3(nrm3[3 * i], nrm3[3 * i + 1], nrm3[3 * i + 2]));
+  Bsdf<5> b;
+  b.len = 0;
+  b.ng = normal;
+  b.onb = onb_from_w(normal);
+  compute_bsdf<ALL, 5>(S, inst, uv2{uv2_[2 * i], uv2_[2 * i + 1]}, b);
+  f3 wo = mk3(wo3[3 * i], wo3[3 * i + 1], wo3[3 * i + 2]), wi = mk3(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]);
+  f3 f = bsdf_f<5, true>(b, wo, wi);
+  float p = b.len ? bsdf_pdf<5, true>(b, wo, wi) : 0.0f;
+  Pcg rng = pcg_new(seeds[i]);
+  Sampled sf = bsdf_sample<5, true>(b, wo, rng);
+  float* o = out + 12 * (size_t)i;
+  o[0] = f.x; o[1] = f.y; o[2] = f.z; o[3] = p;
+  o[4] = sf.wi.x; o[5] = sf.wi.y; o[6] = sf.wi.z;
+  o[7] = sf.f.x; o[8] = sf.f.y; o[9] = sf.f.z; o[10] = sf.pdf; o[11] = (float)b.len;
+}
+
+hipError_t launch_bsdf_eval(const SceneView& S, uint32_t material, uint32_t n, const float* nrm3, const float* uv,
+                            const float* wo3, const float* wi3, const uint32_t* seeds, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(bsdf_eval_kernel, dim3((n + 63) / 64), dim3(64), 0, st, S, material, n, nrm3, uv, wo3, wi3, seeds, out);
+  return hipGetLastError();
+}
+
 // =================================================================================================
 // host-side dispatch
 // =================================================================================================

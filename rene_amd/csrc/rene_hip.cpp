@@ -60,7 +60,7 @@ struct rene_ctx {
   std::vector<void*> allocations;
   rene::SceneView view{};
   rene::LaunchConfig cfg{};
-  uint32_t width = 0, height = 0, tiles_x = 0, n_tiles = 0, n_work = 0;
+  uint32_t width = 0, height = 0, tiles_x = 0, n_tiles = 0, n_work = 0, n_materials = 0;
   float* fb = nullptr;
   bool own_fb = false;
   size_t fb_floats = 0;
@@ -179,6 +179,7 @@ int rene_create(const rene_scene_desc* scene, const rene_opts* opts, rene_ctx** 
   c->seed_gen = HostPcg(o.seed);
   c->width = ps.width;
   c->height = ps.height;
+  c->n_materials = (uint32_t)ps.materials.size();
   struct Cleanup {
     std::unique_ptr<rene_ctx>& c;
     bool armed = true;
@@ -445,6 +446,30 @@ int rene_trace(rene_ctx* c, int which, size_t n, const float* origins, const flo
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   cleanup();
   if (e != hipSuccess) return fail(RENE_ERR_DEVICE, std::string("rene_trace: ") + hipGetErrorString(e));
+  return RENE_OK;
+}
+
+int rene_bsdf_eval(rene_ctx* c, uint32_t material_index, size_t n, const float* normals3, const float* uvs2,
+                   const float* wo3, const float* wi3, const uint32_t* seeds, float* out12) {
+  if (!c || (n && (!normals3 || !uvs2 || !wo3 || !wi3 || !seeds || !out12)))
+    return fail(RENE_ERR_INVALID_ARGUMENT, "rene_bsdf_eval: NULL argument");
+  if (material_index >= c->n_materials) return fail(RENE_ERR_INVALID_ARGUMENT, "material_index out of range");
+  if (n == 0) return RENE_OK;
+  if (n > (1u << 24)) return fail(RENE_ERR_INVALID_ARGUMENT, "too many items in one batch");
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t sizes[6] = {n * 12, n * 8, n * 12, n * 12, n * 4, n * 48};
+  const void* src[5] = {normals3, uvs2, wo3, wi3, seeds};
+  void* d[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipError_t e = hipSuccess;
+  for (int i = 0; i < 6 && e == hipSuccess; ++i) e = hipMalloc(&d[i], sizes[i]);
+  for (int i = 0; i < 5 && e == hipSuccess; ++i) e = hipMemcpyAsync(d[i], src[i], sizes[i], hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess)
+    e = rene::launch_bsdf_eval(c->view, material_index, (uint32_t)n, (const float*)d[0], (const float*)d[1],
+                               (const float*)d[2], (const float*)d[3], (const uint32_t*)d[4], (float*)d[5], c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(out12, d[5], sizes[5], hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  for (int i = 0; i < 6; ++i) hipFree(d[i]);
+  if (e != hipSuccess) return fail(RENE_ERR_DEVICE, std::string("rene_bsdf_eval: ") + hipGetErrorString(e));
   return RENE_OK;
 }
 

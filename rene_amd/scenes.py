@@ -90,3 +90,99 @@ def cornell_box(xres: int = 1024, yres: int = 1024) -> Scene:
                                -0.24, 1.98, 0.16], (-8.74228e-08, -1, 1.86006e-07)),
                         mat["Light"], area_light=light)
     return s
+
+
+# ---------------------------------------------------------------------------------------------------
+# veach-mis (BASELINE config 3): numbers from sample_scenes/veach-mis/scene.pbrt (Bitterli, CC0)
+# ---------------------------------------------------------------------------------------------------
+VEACH_WORLD_TO_CAMERA = [4.37113e-08, -0, -1, -0, -0, 1, -0, -0, -1, -0, -4.37113e-08, -0, -0, -3.5, 28.2792, 1]
+VEACH_FOV_DEG = 20.114292
+_VEACH_ETA = (0.200438, 0.924033, 1.102212)
+_VEACH_K = (3.912949, 2.452848, 2.142188)
+
+
+def _plate(A, B, Cc, D, n0, n4) -> TriangleMesh:
+    """A box extruded along z in [-4, 4] from the cross-section A, B, D, C; vertex order as in the file."""
+    def v(p, z):
+        return [p[0], p[1], z]
+    P = [v(A, -4), v(A, 4), v(B, 4), v(B, -4), v(Cc, 4), v(Cc, -4), v(D, -4), v(D, 4),
+         v(Cc, -4), v(A, -4), v(B, -4), v(D, -4), v(D, 4), v(B, 4), v(A, 4), v(Cc, 4),
+         v(Cc, 4), v(A, 4), v(A, -4), v(Cc, -4), v(D, -4), v(B, -4), v(B, 4), v(D, 4)]
+    neg = lambda n: tuple(-x for x in n)
+    return _box(np.asarray(P, dtype=F32).reshape(-1), [n0, neg(n0), (0, 0, -1), (0, 0, 1), n4, neg(n4)])
+
+
+def veach_mis(xres: int = 1280, yres: int = 720) -> Scene:
+    """52 triangles + 3 emissive spheres (r = 1, 0.5, 0.05), four metal plates with
+    alpha = 0.01 / 0.05 / 0.1 / 0.25 (`remaproughness false`), two Matte walls."""
+    s = Scene.new()
+    s.film.filename = "veach-mis.png"
+    s.set_camera(glam.from_cols_array(VEACH_WORLD_TO_CAMERA), VEACH_FOV_DEG, xres, yres)
+    diffuse = s.add_matte((0.5, 0.5, 0.5))
+    metal = lambda a: s.add_metal(_VEACH_ETA, _VEACH_K, a, a, remap_roughness=False)
+    smooth, glossy, rough = metal(0.01), metal(0.05), metal(0.1)
+    null = s.add_matte((0.0, 0.0, 0.0))
+    super_rough = metal(0.25)
+    s.add_triangle_mesh(_plate((-0.637866, 4.65614), (0.973649, 3.30966), (-0.445511, 4.88636), (1.166, 3.53988),
+                               (-0.641183, -0.767388, 0), (-0.767388, 0.641183, 0)), smooth)
+    s.add_triangle_mesh(_plate((2.03286, 2.97515), (3.97697, 2.18116), (2.14629, 3.25288), (4.0904, 2.45889),
+                               (-0.37809, -0.925769, 0), (-0.925769, 0.37809, 0)), glossy)
+    s.add_triangle_mesh(_plate((6.04018, 1.86557), (8.10399, 1.47742), (6.09563, 2.1604), (8.15944, 1.77225),
+                               (-0.184835, -0.98277, 0), (-0.98277, 0.184835, 0)), rough)
+    s.add_triangle_mesh(_quad([-5, 8.65485e-07, 23.76, 14.8, 8.65485e-07, 23.76, 14.8, -8.65485e-07, -23.76,
+                               -5, -8.65485e-07, -23.76], (0, 1, -2.09815e-07)), diffuse)
+    s.add_triangle_mesh(_quad([-5, 19.8, 23.76, -5, 0, 23.76, -5, 0, -23.76, -5, 19.8, -23.76],
+                              (1, -4.37114e-08, -2.09815e-07)), diffuse)
+    for L, z, r in ((7.599088, -2.8, 1.0), (30.396353, 0.0, 0.5), (3039.635254, 2.7, 0.05)):
+        al = s.add_area_light_diffuse((L, L, L))
+        s.add_sphere(r, null, area_light=al, ctm=glam.from_translation((0, 6.5, z)))
+    s.add_triangle_mesh(_plate((9.61645, 1.21286), (11.7008, 0.956897), (9.65301, 1.51062), (11.7374, 1.25466),
+                               (-0.121887, -0.992544, 0), (-0.992544, 0.121887, 0)), super_rough)
+    return s
+
+
+# ---------------------------------------------------------------------------------------------------
+# material zoo: every material / texture / light kind the path integrator supports, in one small
+# scene (parity-test input, not a reference scene)
+# ---------------------------------------------------------------------------------------------------
+def material_zoo(xres: int = 96, yres: int = 64) -> Scene:
+    s = Scene.new()
+    s.film.filename = "zoo.png"
+    s.set_camera(glam.look_at_lh((0.0, 2.2, -7.5), (0.0, 0.8, 0.0), (0.0, 1.0, 0.0)), 38.0, xres, yres)
+    rng = np.random.default_rng(5)
+    img = np.ones((16, 32, 4), dtype=F32)
+    img[..., :3] = rng.uniform(0.1, 1.0, (16, 32, 3))
+    sky = np.ones((8, 16, 4), dtype=F32)
+    sky[..., 0], sky[..., 1], sky[..., 2] = 0.35, 0.45, np.linspace(0.9, 0.4, 8)[:, None]
+    s.set_infinite_light((0.8, 0.8, 0.8), image=sky, ctm=glam.from_axis_angle((0.0, 1.0, 0.0), 0.6))
+    s.add_light_distant((-0.3, 0.8, -0.5), (0, 0, 0), (1.5, 1.4, 1.2))
+    dark, light = s.add_texture_solid((0.15, 0.15, 0.2)), s.add_texture_solid((0.8, 0.8, 0.7))
+    checks = s.add_texture_checkerboard(dark, light, 8.0, 8.0)
+    imap = s.add_texture_image_map(img)
+    scale = s.add_texture_scale(imap, light)
+    floor = TriangleMesh.from_arrays([-6, 0, -6, 6, 0, -6, 6, 0, 6, -6, 0, 6], _QUAD_IDX, uvs=_QUAD_UV)  # no normals
+    s.add_triangle_mesh(floor, s.add_matte(checks))
+    back = TriangleMesh.from_arrays([-6, 0, 4, 6, 0, 4, 6, 5, 4, -6, 5, 4], _QUAD_IDX, normals=[(0, 0, -1)] * 4, uvs=_QUAD_UV)
+    s.add_triangle_mesh(back, s.add_matte(scale))
+    mats = [s.add_glass(1.5), s.add_mirror((0.9, 0.85, 0.8)),
+            s.add_metal(_VEACH_ETA, _VEACH_K, 0.2, 0.05, remap_roughness=False),
+            s.add_substrate((0.6, 0.2, 0.2), (0.04, 0.04, 0.04), 0.05, 0.05, remap_roughness=True),
+            s.add_plastic((0.2, 0.5, 0.3), (0.3, 0.3, 0.3), 0.15),
+            s.add_uber(kd=(0.3, 0.3, 0.6), ks=(0.2, 0.2, 0.2), kr=(0.1, 0.1, 0.1), kt=(0.3, 0.3, 0.3),
+                       opacity=(0.7, 0.7, 0.7), rough_u=0.1, rough_v=0.2, eta=1.4)]
+    for i, m in enumerate(mats):
+        s.add_sphere(0.6, m, ctm=glam.from_translation((-3.75 + 1.5 * i, 0.6, 0.5 * (i % 2))))
+    tri_light = s.add_area_light_diffuse((8.0, 7.0, 6.0))
+    lq = TriangleMesh.from_arrays([-1, 4, -1, 1, 4, -1, 1, 4, 1, -1, 4, 1], _QUAD_IDX, normals=[(0, -1, 0)] * 4)
+    s.add_triangle_mesh(lq, 0, area_light=tri_light, ctm=glam.mul(glam.from_translation((0.5, 0.0, 0.0)), glam.from_scale((1.5, 1.0, 0.5))))
+    sph_light = s.add_area_light_diffuse((20.0, 20.0, 30.0))
+    s.add_sphere(0.25, s.add_matte((0, 0, 0)), area_light=sph_light, ctm=glam.from_translation((-3.0, 2.5, -1.0)))
+    # an instanced, mirrored (negative determinant) mesh with a textured metal
+    cube_p = [-1, 0, -1, 1, 0, -1, 1, 0, 1, -1, 0, 1, -1, 1, -1, 1, 1, -1, 1, 1, 1, -1, 1, 1]
+    cube_i = [0, 2, 1, 0, 3, 2, 4, 5, 6, 4, 6, 7, 0, 1, 5, 0, 5, 4, 1, 2, 6, 1, 6, 5, 2, 3, 7, 2, 7, 6, 3, 0, 4, 3, 4, 7]
+    cube = TriangleMesh.from_arrays(cube_p, cube_i)
+    ci = s.add_triangle_mesh(cube, s.add_metal(imap, _VEACH_K, 0.3, 0.3, remap_roughness=False),
+                             ctm=glam.mul(glam.from_translation((3.6, 0.0, 2.2)), glam.from_scale((0.5, 0.8, 0.5))))
+    s.add_mesh_instance(s.instances[ci].mesh_index, mats[4],
+                        ctm=glam.mul(glam.from_translation((-4.2, 0.0, 2.4)), glam.from_scale((-0.4, 0.6, 0.4))))
+    return s
