@@ -175,6 +175,100 @@ RENE_DEV HitRec traverse(const Accel& A, const Sphere* spheres, f3 o, f3 d, floa
   }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Small scenes: wave-coherent loop over every item (device_scene.h, SmallItem).  The item index is
+// wave-uniform, so the 64-byte record is fetched once per wave through the scalar cache (s_load)
+// and its fields are SGPR operands of the per-lane arithmetic; there is no stack, no divergent
+// control flow and no vector memory traffic.  A parallelogram item covers two triangles.
+// -------------------------------------------------------------------------------------------------
+typedef const __attribute__((address_space(4))) float* cfloat_ptr;  // constant address space -> SMEM loads
+
+template <bool ANY, bool SPHERES, bool COUNT>
+RENE_DEV HitRec traverse_small(const Accel& A, const Sphere* spheres, f3 o, f3 d, float tmin, float tmax,
+                               LaneCounters& lc) {
+  float best_t = tmax, best_s = 0.0f, best_r = 0.0f;
+  uint32_t best_item = 0xffffffffu;
+  const uint32_t n = A.n_items;
+  cfloat_ptr base = (cfloat_ptr)(const void*)A.items;
+  for (uint32_t k = 0; k < n; ++k) {
+    cfloat_ptr q = base + 16 * k;
+    const uint32_t kind = __float_as_uint(q[9]);
+    if (COUNT) lc.prims++;
+    if (SPHERES && kind == SMALL_SPHERE) {  // sphere_intersection, lib.rs:805-839
+      uint32_t slot = __float_as_uint(q[10]);
+      uint32_t sidx = __float_as_uint(A.isect[slot].q[11]);
+      const float* w2o = spheres[sidx].w2o;
+      f3 oc = aff_point(w2o, o);
+      f3 od = aff_vector(w2o, d);
+      float a = length_squared(od);
+      float half_b = dot(oc, od);
+      float c = length_squared(oc) - 1.0f;
+      float disc = half_b * half_b - a * c;
+      if (disc >= 0.0f) {
+        float sq = sqrtf(disc);
+        float root0 = (-half_b - sq) / a;
+        float root1 = (-half_b + sq) / a;
+        float r = -1.0f;
+        if (root0 >= tmin && root0 <= best_t) r = root0;
+        else if (root1 >= tmin && root1 <= best_t) r = root1;
+        if (r >= tmin && (best_item == 0xffffffffu ? r <= best_t : r < best_t)) {
+          best_t = r;
+          best_s = 0.0f;
+          best_r = 0.0f;
+          best_item = k;
+        }
+      }
+      continue;
+    }
+    f3 O = mk3(q[0], q[1], q[2]), ea = mk3(q[3], q[4], q[5]), eb = mk3(q[6], q[7], q[8]);
+    f3 pv = cross(d, eb);
+    float det = dot(ea, pv);
+    float inv_det = __builtin_amdgcn_rcpf(det);  // 1 ulp; det == 0 -> inf -> rejected below
+    f3 tv = o - O;
+    float s = dot(tv, pv) * inv_det;
+    f3 qv = cross(tv, ea);
+    float r = dot(d, qv) * inv_det;
+    float t = dot(eb, qv) * inv_det;
+    // triangle: s, r >= 0 and s + r <= 1; parallelogram: s, r in [0, 1].  det == 0 gives inf/nan -> rejected
+    bool inside = s >= 0.0f && r >= 0.0f && (kind == SMALL_QUAD ? (s <= 1.0f && r <= 1.0f) : (s + r <= 1.0f));
+    bool accept = inside && t >= tmin && (best_item == 0xffffffffu ? t <= best_t : t < best_t);
+    if (accept) {
+      best_t = t;
+      best_s = s;
+      best_r = r;
+      best_item = k;
+    }
+  }
+  HitRec h;
+  h.t = best_t;
+  h.u = 0.0f;
+  h.v = 0.0f;
+  h.slot = 0xffffffffu;
+  if (best_item != 0xffffffffu) {
+    // map (item, s, r) back to (triangle slot, barycentric u, v) of the BVH path's conventions
+    const float* q = A.items[best_item].q;
+    float4 m = ldg4(q + 8);   // b.z, kind, slot1, slot2
+    float4 pm = ldg4(q + 12);  // perm1, perm2
+    bool second = __float_as_uint(m.y) == SMALL_QUAD && best_s + best_r > 1.0f;
+    uint32_t perm = __float_as_uint(second ? pm.y : pm.x);
+    float w0 = second ? best_s + best_r - 1.0f : 1.0f - best_s - best_r;
+    float w1 = second ? 1.0f - best_r : best_s;
+    float w2 = second ? 1.0f - best_s : best_r;
+    uint32_t iu = perm & 3u, iv = (perm >> 2) & 3u;
+    h.u = iu == 0u ? w0 : (iu == 1u ? w1 : w2);
+    h.v = iv == 0u ? w0 : (iv == 1u ? w1 : w2);
+    h.slot = __float_as_uint(second ? m.w : m.z);
+  }
+  return h;
+}
+
+template <bool SMALL, bool ANY, bool SPHERES, bool COUNT>
+RENE_DEV HitRec trace_accel(const Accel& A, const Sphere* spheres, f3 o, f3 d, float tmin, float tmax,
+                            uint32_t* stack, LaneCounters& lc) {
+  if (SMALL) return traverse_small<ANY, SPHERES, COUNT>(A, spheres, o, d, tmin, tmax, lc);
+  return traverse<ANY, SPHERES, COUNT>(A, spheres, o, d, tmin, tmax, stack, lc);
+}
+
 // =================================================================================================
 // textures / materials / BSDF
 // =================================================================================================
@@ -929,6 +1023,7 @@ template <uint32_t FEAT, int MAXL, bool COUNT, bool AOV>
 __global__ void __launch_bounds__(BLOCK) render_kernel(SceneView S, RenderParams P) {
   constexpr bool SPHERES = (FEAT & FEAT_SPHERES) != 0;
   constexpr bool GENERAL = (FEAT & FEAT_GENERAL_BSDF) != 0;
+  constexpr bool SMALL = (FEAT & FEAT_SMALL) != 0;
   extern __shared__ uint32_t s_stack[];  // [stack depth][BLOCK]
   uint32_t* stack = s_stack + threadIdx.x;
 
@@ -1016,7 +1111,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneView S, RenderParams
     // ---- one bounce, lib.rs:192-355 ------------------------------------------------------------------
     if (active) {
       lc.closest++;
-      HitRec h = traverse<false, SPHERES, COUNT>(S.main, S.spheres, ro, rd, tmin, tmax, stack, lc);
+      HitRec h = trace_accel<SMALL, false, SPHERES, COUNT>(S.main, S.spheres, ro, rd, tmin, tmax, stack, lc);
       if (h.slot == 0xffffffffu) {  // main_miss, lib.rs:120-139, 209-211
         f3 bg = splat(0.0f);
         if (FEAT & FEAT_BACKGROUND) {
@@ -1057,7 +1152,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneView S, RenderParams
             f3 target = position + mk3(ld.x, ld.y, ld.z);  // light.rs:52-55
             f3 wi = normalize(target - position);
             lc.shadow++;
-            HitRec sh = traverse<true, SPHERES, COUNT>(S.main, S.spheres, position, wi, tmin, 1e5f, stack, lc);
+            HitRec sh = trace_accel<SMALL, true, SPHERES, COUNT>(S.main, S.spheres, position, wi, tmin, 1e5f, stack, lc);
             if (sh.slot == 0xffffffffu) {
               f3 f = bsdf_f<MAXL, GENERAL>(bsdf, wo, wi);
               acc0 = acc0 + color * f * fabsf(dot(wi, normal)) * mk3(lL.x, lL.y, lL.z);
@@ -1083,7 +1178,7 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneView S, RenderParams
           ro = position;
           rd = wi;
           lc.emitter++;
-          HitRec eh = traverse<false, SPHERES, COUNT>(S.emit, S.spheres, ro, rd, tmin, tmax, stack, lc);  // Q5
+          HitRec eh = trace_accel<SMALL, false, SPHERES, COUNT>(S.emit, S.spheres, ro, rd, tmin, tmax, stack, lc);  // Q5
           float pdf_l = emitter_pdf<SPHERES>(S, eh, ro, rd);
           color = color * (f * fabsf(dot(normal, wi)));
           pdf = 0.5f * pdf + 0.5f * pdf_l / (float)S.emit_object_len;
@@ -1127,16 +1222,19 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneView S, RenderParams
 // -------------------------------------------------------------------------------------------------
 // batch closest-hit queries (rene_trace): one lane per ray
 // -------------------------------------------------------------------------------------------------
+template <bool SMALL>
 __global__ void __launch_bounds__(BLOCK) trace_kernel(SceneView S, int which, uint32_t n, const float* o3,
                                                       const float* d3, float tmin, float tmax, rene_hit* out) {
   extern __shared__ uint32_t s_stack[];
   uint32_t* stack = s_stack + threadIdx.x;
   uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-  if (i >= n) return;
+  const bool live = i < n;
+  if (!live) i = n - 1;  // keep the wave converged for the coherent item loop
   LaneCounters lc;
   f3 o = mk3(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]), d = mk3(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]);
   const Accel& A = which ? S.emit : S.main;
-  HitRec h = traverse<false, true, false>(A, S.spheres, o, d, tmin, tmax, stack, lc);
+  HitRec h = trace_accel<SMALL, false, true, false>(A, S.spheres, o, d, tmin, tmax, stack, lc);
+  if (!live) return;
   rene_hit r;
   if (h.slot == 0xffffffffu) {
     r.t = -1.0f; r.u = 0.0f; r.v = 0.0f; r.instance = 0; r.primitive = 0;
@@ -1195,7 +1293,7 @@ hipError_t launch_bsdf_eval(const SceneView& S, uint32_t material, uint32_t n, c
 // =================================================================================================
 template <uint32_t FEAT, int MAXL>
 static hipError_t launch_feat(const LaunchConfig& cfg, const SceneView& S, const RenderParams& P, hipStream_t st) {
-  size_t lds = (size_t)cfg.stack_depth * BLOCK * sizeof(uint32_t);
+  size_t lds = (FEAT & FEAT_SMALL) ? 0 : (size_t)cfg.stack_depth * BLOCK * sizeof(uint32_t);
   dim3 grid(cfg.grid), block(BLOCK);
   bool count = (P.flags & RENE_FLAG_COUNTERS) != 0, aov = !(P.flags & RENE_FLAG_NO_AOV);
   if (count) {
@@ -1209,22 +1307,25 @@ static hipError_t launch_feat(const LaunchConfig& cfg, const SceneView& S, const
 }
 
 hipError_t launch_render(const LaunchConfig& cfg, const SceneView& S, const RenderParams& P, hipStream_t st) {
-  // Two specialisations: the Matte-only fast path (Cornell, dragon-class) and the general one.
+  // Specialisations: Matte-only fast path (Cornell, dragon-class), general single-lobe, general
+  // multi-lobe; each with the BVH traversal or, for tiny scenes, the wave-coherent item loop.
   constexpr uint32_t ALL = FEAT_SPHERES | FEAT_GENERAL_BSDF | FEAT_TEXTURES | FEAT_LIGHTS | FEAT_BACKGROUND | FEAT_MULTI_LOBE;
+  constexpr uint32_t GEN1 = ALL & ~FEAT_MULTI_LOBE;
   const uint32_t f = cfg.features;
-  if (!(f & (FEAT_SPHERES | FEAT_GENERAL_BSDF | FEAT_TEXTURES | FEAT_BACKGROUND | FEAT_MULTI_LOBE))) {
-    if (f & FEAT_LIGHTS) return launch_feat<FEAT_LIGHTS, 1>(cfg, S, P, st);
-    return launch_feat<0u, 1>(cfg, S, P, st);
-  }
-  if (!(f & FEAT_MULTI_LOBE)) return launch_feat<ALL & ~FEAT_MULTI_LOBE, 1>(cfg, S, P, st);
-  return launch_feat<ALL, 5>(cfg, S, P, st);
+  const bool small = (f & FEAT_SMALL) != 0;
+  if (!(f & (FEAT_SPHERES | FEAT_GENERAL_BSDF | FEAT_TEXTURES | FEAT_BACKGROUND | FEAT_MULTI_LOBE)))
+    return small ? launch_feat<FEAT_LIGHTS | FEAT_SMALL, 1>(cfg, S, P, st) : launch_feat<FEAT_LIGHTS, 1>(cfg, S, P, st);
+  if (!(f & FEAT_MULTI_LOBE))
+    return small ? launch_feat<GEN1 | FEAT_SMALL, 1>(cfg, S, P, st) : launch_feat<GEN1, 1>(cfg, S, P, st);
+  return small ? launch_feat<ALL | FEAT_SMALL, 5>(cfg, S, P, st) : launch_feat<ALL, 5>(cfg, S, P, st);
 }
 
 hipError_t launch_trace(const LaunchConfig& cfg, const SceneView& S, int which, uint32_t n, const float* o,
                         const float* d, float tmin, float tmax, rene_hit* out, hipStream_t st) {
   size_t lds = (size_t)cfg.stack_depth * BLOCK * sizeof(uint32_t);
-  hipLaunchKernelGGL(trace_kernel, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), lds, st, S, which, n, o, d, tmin,
-                     tmax, out);
+  dim3 grid((n + BLOCK - 1) / BLOCK), block(BLOCK);
+  if (cfg.features & FEAT_SMALL) hipLaunchKernelGGL(trace_kernel<true>, grid, block, 0, st, S, which, n, o, d, tmin, tmax, out);
+  else hipLaunchKernelGGL(trace_kernel<false>, grid, block, lds, st, S, which, n, o, d, tmin, tmax, out);
   return hipGetLastError();
 }
 

@@ -208,6 +208,10 @@ int rene_create(const rene_scene_desc* scene, const rene_opts* opts, rene_ctx** 
   UP(ps.main.isect, v.main.isect);
   UP(ps.emit.nodes, v.emit.nodes);
   UP(ps.emit.isect, v.emit.isect);
+  UP(ps.main.items, v.main.items);
+  UP(ps.emit.items, v.emit.items);
+  v.main.n_items = (uint32_t)ps.main.items.size();
+  v.emit.n_items = (uint32_t)ps.emit.items.size();
   v.main.n_nodes = (uint32_t)ps.main.nodes.size();
   v.main.n_slots = (uint32_t)ps.main.isect.size();
   v.emit.n_nodes = (uint32_t)ps.emit.nodes.size();
@@ -240,6 +244,7 @@ int rene_create(const rene_scene_desc* scene, const rene_opts* opts, rene_ctx** 
   while (stack < depth) stack += 16;
   if (stack > 96) return fail(RENE_ERR_UNSUPPORTED, "BVH deeper than the 96-entry traversal stack");
   c->cfg.features = ps.features;
+  if (o.flags & RENE_FLAG_FORCE_BVH) c->cfg.features &= ~rene::FEAT_SMALL;
   c->cfg.stack_depth = stack;
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, o.device));

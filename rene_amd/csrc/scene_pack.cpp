@@ -260,6 +260,93 @@ struct Builder {
   }
 };
 
+inline uint32_t float_bits(float f) {
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  return u;
+}
+
+// Small-scene item list over the slots of a built structure: merge triangle pairs of one instance
+// that share an edge X-Y and whose third vertices satisfy Z1 + Z2 = X + Y (a parallelogram).
+void build_small_items(BuiltAccel& acc) {
+  acc.items.clear();
+  const size_t n = acc.isect.size();
+  if (n == 0 || n > 2 * SMALL_MAX_ITEMS) return;
+  struct Tri { V3 v[3]; uint32_t inst, prim; bool sphere; };
+  std::vector<Tri> t(n);
+  for (size_t s = 0; s < n; ++s) {
+    const float* q = acc.isect[s].q;
+    t[s].sphere = float_bits(q[11]) != 0xffffffffu;
+    t[s].inst = float_bits(q[9]);
+    t[s].prim = float_bits(q[10]);
+    t[s].v[0] = V3{q[0], q[1], q[2]};
+    t[s].v[1] = V3{q[0] + q[3], q[1] + q[4], q[2] + q[5]};
+    t[s].v[2] = V3{q[0] + q[6], q[1] + q[7], q[2] + q[8]};
+  }
+  auto close = [](V3 a, V3 b, float tol) {
+    return std::fabs(a.x - b.x) <= tol && std::fabs(a.y - b.y) <= tol && std::fabs(a.z - b.z) <= tol;
+  };
+  std::vector<char> used(n, 0);
+  auto emit_tri = [&](size_t s) {
+    SmallItem it;
+    std::memset(&it, 0, sizeof(it));
+    const float* q = acc.isect[s].q;
+    for (int k = 0; k < 9; ++k) it.q[k] = q[k];  // O = p0, a = e1, b = e2: identical operands to the BVH path
+    it.q[9] = bits_to_float(t[s].sphere ? SMALL_SPHERE : SMALL_TRIANGLE);
+    it.q[10] = bits_to_float((uint32_t)s);
+    it.q[11] = bits_to_float((uint32_t)s);
+    it.q[12] = bits_to_float(1u | (2u << 2));  // u = weight of O+a, v = weight of O+b
+    it.q[13] = bits_to_float(1u | (2u << 2));
+    acc.items.push_back(it);
+  };
+  for (size_t i = 0; i < n; ++i) {
+    if (used[i]) continue;
+    used[i] = 1;
+    if (t[i].sphere) { emit_tri(i); continue; }
+    bool merged = false;
+    for (size_t j = i + 1; j < n && !merged; ++j) {
+      if (used[j] || t[j].sphere || t[j].inst != t[i].inst) continue;
+      // scale-aware tolerance
+      float scale = 0.f;
+      for (int k = 0; k < 3; ++k)
+        scale = std::max(scale, std::max(std::fabs(t[i].v[k].x), std::max(std::fabs(t[i].v[k].y), std::fabs(t[i].v[k].z))));
+      float tol = 4e-6f * std::max(scale, 1e-3f);
+      // find the shared edge: vertices of i matching vertices of j
+      int mi[3] = {-1, -1, -1};
+      int shared = 0;
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b)
+          if (mi[a] < 0 && close(t[i].v[a], t[j].v[b], tol)) { mi[a] = b; shared++; break; }
+      if (shared != 2) continue;
+      int zi = mi[0] < 0 ? 0 : (mi[1] < 0 ? 1 : 2);       // third vertex of i
+      int xi = (zi + 1) % 3, yi = (zi + 2) % 3;          // shared edge in i's winding
+      int zj = 3 - mi[xi] - mi[yi];                        // third vertex of j
+      V3 Z1 = t[i].v[zi], X = t[i].v[xi], Y = t[i].v[yi], Z2 = t[j].v[zj];
+      V3 lhs{Z1.x + Z2.x, Z1.y + Z2.y, Z1.z + Z2.z}, rhs{X.x + Y.x, X.y + Y.y, X.z + Y.z};
+      if (!close(lhs, rhs, tol)) continue;
+      SmallItem it;
+      std::memset(&it, 0, sizeof(it));
+      V3 a = sub(X, Z1), b = sub(Y, Z1);
+      it.q[0] = Z1.x; it.q[1] = Z1.y; it.q[2] = Z1.z;
+      it.q[3] = a.x; it.q[4] = a.y; it.q[5] = a.z;
+      it.q[6] = b.x; it.q[7] = b.y; it.q[8] = b.z;
+      it.q[9] = bits_to_float(SMALL_QUAD);
+      it.q[10] = bits_to_float((uint32_t)i);
+      it.q[11] = bits_to_float((uint32_t)j);
+      // generic corner index (0 = O / far corner, 1 = X, 2 = Y) of each triangle's v1 and v2
+      auto corner_i = [&](int v) { return v == zi ? 0u : (v == xi ? 1u : 2u); };
+      auto corner_j = [&](int v) { return v == zj ? 0u : (v == mi[xi] ? 1u : 2u); };
+      it.q[12] = bits_to_float(corner_i(1) | (corner_i(2) << 2));
+      it.q[13] = bits_to_float(corner_j(1) | (corner_j(2) << 2));
+      acc.items.push_back(it);
+      used[j] = 1;
+      merged = true;
+    }
+    if (!merged) emit_tri(i);
+  }
+  if (acc.items.size() > SMALL_MAX_ITEMS) acc.items.clear();
+}
+
 void finish_accel(const std::vector<Prim>& prims, uint32_t max_leaf, BuiltAccel& out,
                   std::vector<uint32_t>& order) {
   Builder b(prims, max_leaf);
@@ -269,6 +356,7 @@ void finish_accel(const std::vector<Prim>& prims, uint32_t max_leaf, BuiltAccel&
   out.isect.resize(prims.size());
   for (size_t s = 0; s < prims.size(); ++s) out.isect[s] = prims[b.order[s]].isect;
   order = std::move(b.order);
+  build_small_items(out);
 }
 
 }  // namespace
@@ -501,6 +589,7 @@ int pack_scene(const rene_scene_desc* d, PackedScene& out, std::string& err) {
   finish_accel(eprims, 4, out.emit, order);
   out.emit_pdf.resize(eprims.size());
   for (size_t s = 0; s < eprims.size(); ++s) out.emit_pdf[s] = eprims[order[s]].pdf;
+  if (!out.main.items.empty() && (eprims.empty() || !out.emit.items.empty())) out.features |= FEAT_SMALL;
   return RENE_OK;
 }
 

@@ -13,6 +13,7 @@ namespace rene {
 struct BuiltAccel {
   std::vector<Node> nodes;
   std::vector<PrimIsect> isect;  // slot order
+  std::vector<SmallItem> items;  // small-scene item list (empty if the structure is too large)
   uint32_t depth = 0;            // max stack depth a traversal can need
 };
 

@@ -8,10 +8,10 @@ from test_gpu_parity import aov_check, t1_check
 pytestmark = pytest.mark.gpu
 
 
-def _compare(scene, frames, oracle_mod, frac, relmse, ctol):
+def _compare(scene, frames, oracle_mod, frac, relmse, ctol, flags=0):
     o = oracle_mod.Oracle(scene)
     o.render(0, frames)
-    with api.Renderer(scene, flags=abi.FLAG_COUNTERS) as r:
+    with api.Renderer(scene, flags=abi.FLAG_COUNTERS | flags) as r:
         r.render(0, frames)
         so, sg = o.stats().as_dict(), r.stats().as_dict()
         print({k: (sg[k], so[k]) for k in ("rays_closest", "rays_emitter", "rays_shadow", "hits", "adds")})
@@ -37,16 +37,18 @@ def test_veach_mis_metal_and_sphere_emitters(oracle_mod):
     # so ANY two fp32 evaluations (FMA or not, this GPU or a Vulkan one) differ by 1-30 % on samples that
     # see that light.  tests/test_oracle_fp_sensitivity.py shows the same spread between two CPU builds
     # of the oracle.  Hence: image-level agreement tight (relMSE, mean), per-pixel agreement loose.
-    sg, so = _compare(s, 16, oracle_mod, frac=0.12, relmse=1e-5, ctol=2e-3)
-    assert sg["rays_emitter"] > 0 and sg["rays_shadow"] == 0
+    for flags in (0, abi.FLAG_FORCE_BVH):
+        sg, so = _compare(s, 16, oracle_mod, frac=0.12, relmse=1e-4, ctol=2e-3, flags=flags)
+        assert sg["rays_emitter"] > 0 and sg["rays_shadow"] == 0
 
 
 def test_material_zoo_every_kind(oracle_mod):
     # glass / mirror / metal / substrate / plastic / uber, checkerboard + imagemap + scale textures,
     # env-map background, a distant light, triangle + sphere emitters, a mirrored instance
     s = scenes.material_zoo(96, 64)
-    sg, so = _compare(s, 32, oracle_mod, frac=1e-2, relmse=2e-3, ctol=3e-3)
-    assert sg["rays_shadow"] > 0
+    for flags in (0, abi.FLAG_FORCE_BVH):
+        sg, so = _compare(s, 32, oracle_mod, frac=1e-2, relmse=2e-3, ctol=3e-3, flags=flags)
+        assert sg["rays_shadow"] > 0
 
 
 def test_traversal_with_spheres(oracle_mod):
@@ -57,7 +59,8 @@ def test_traversal_with_spheres(oracle_mod):
     org = np.stack([rng.uniform(-5, 5, n), rng.uniform(0.1, 3.5, n), rng.uniform(-7, 3, n)], 1).astype(np.float32)
     d = rng.normal(size=(n, 3))
     d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
-    with api.Renderer(s) as r:
+    for flags in (0, abi.FLAG_FORCE_BVH):
+      with api.Renderer(s, flags=flags) as r:
         for which in (0, 1):
             hg, ho = r.trace(org, d, which=which), o.trace(org, d, which=which)
             mg, mo = hg["t"] < 0, ho["t"] < 0
