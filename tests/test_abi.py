@@ -89,7 +89,7 @@ def test_pack_info_cornell(hip_lib):
     info = api.pack_info(scenes.cornell_box(64, 64)).as_dict()
     assert info["n_triangles"] == 36 and info["n_instances"] == 8 and info["n_spheres"] == 0
     assert info["emit_object_len"] == 1 and info["lights_len"] == 0 and info["n_slots_emit"] == 2
-    assert info["features"] == 0  # Matte-only fast path
+    assert info["features"] == 64  # Matte-only fast path + FEAT_SMALL (wave-coherent item loop)
     assert info["n_slots_main"] == 36 and 1 <= info["n_nodes_main"] < 36
 
 
