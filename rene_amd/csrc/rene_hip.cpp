@@ -52,6 +52,10 @@ struct HostPcg {
 
 }  // namespace
 
+namespace rene {
+void set_last_error(const std::string& msg) { g_error = msg; }
+}
+
 struct rene_ctx {
   int device = 0;
   hipStream_t stream = nullptr;

@@ -1,0 +1,310 @@
+"""The pbrt-v3 loader (C++, rene_amd/csrc/pbrt_loader.cpp).
+
+The first block mirrors the reference's 10 parser tests (pbrt-parser/src/lib.rs:579-711) one for one
+-- the only tests the reference has.  Our parser is not combinator based, so each reference test of
+a sub-parser is restated as the smallest scene that exercises the same lexical rule, and the
+parsed value is read back through the scene tables."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import REFERENCE, have_reference
+from rene_amd import abi, api, loader, scenes
+
+
+def parse(text, base_dir=""):
+    return loader.parse_pbrt(text, base_dir)
+
+
+def film_of(text):
+    s = parse(text)
+    return s.xres, s.yres, s.film_filename
+
+
+WORLD = "\nWorldBegin\nWorldEnd\n"
+
+
+# ---- mirrors of pbrt-parser/src/lib.rs:579-711 -------------------------------------------------------
+def test_comment(hip_lib):  # test_comment: `# Hello` alone is a valid (empty) scene
+    s = parse("# Hello")
+    assert s.desc.n_instances == 0
+
+
+def test_sp(hip_lib):  # test_sp: comments, blank lines, nothing
+    for src in ("# Hello\n   \n", "# hello\n        # world", "\n   \n", " ", ""):
+        parse(src)
+
+
+def _sphere_radius(num: str) -> float:
+    s = parse(f'WorldBegin\nShape "sphere" "float radius" {num}\nWorldEnd')
+    return float(s.desc.instances[0].matrix[0])  # CTM * scale(radius)
+
+
+def test_float(hip_lib):  # test_float: 1, 2.25, 1e5, 1e-5, .9
+    assert _sphere_radius("1") == 1.0
+    assert _sphere_radius("2.25") == 2.25
+    assert _sphere_radius("1e5") == np.float32(1e5)
+    assert _sphere_radius("1e-5") == np.float32(1e-5)
+    assert _sphere_radius(".9") == np.float32(0.9)
+
+
+def test_integer(hip_lib):  # test_integer: 1, 114514, -200
+    assert film_of('Film "image" "integer xresolution" 1 "integer yresolution" 114514' + WORLD)[:2] == (1, 114514)
+    s = parse('WorldBegin\nMaterial "matte"\nShape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd')
+    assert s.tables()["meshes"][0][1].tolist() == [0, 1, 2]
+    with pytest.raises(api.ReneError):  # -200 parses as an integer but is not a valid index
+        parse('WorldBegin\nShape "trianglemesh" "integer indices" [0 1 -200] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd')
+
+
+def test_string(hip_lib):  # test_string: "TEST"
+    assert film_of('Film "image" "string filename" "TEST"' + WORLD)[2] == "TEST"
+    assert film_of('Film "image" "string filename" [ "a\\\\b\\"c" ]' + WORLD)[2] == 'a\\b"c'  # escapes, lib.rs:161-171
+
+
+def test_parse_vec4(hip_lib):  # test_parse_vec4: comments between the numbers of a list
+    src = 'Transform [ 1 # this is 1\n # aaa\n 0 0 0   0 1 0 0   0 0 1 0   2 # this is 2\n 3\n 4 1 ]' + WORLD
+    c2w = np.array(parse(src).desc.uniform.camera_to_world[:]).reshape(4, 4).T
+    np.testing.assert_allclose(c2w[:3, 3], [-2, -3, -4])
+
+
+def test_parse_argument(hip_lib):  # test_parse_argument: "string test" "OK"; "float test" [1 2 3]; "rgb Kd" [ .7 .2 .2 ]
+    s = parse('WorldBegin\nMaterial "matte" "rgb Kd" [ .7 .2 .2 ] "string test" "OK" "float other" [1 2 3]\n'
+              'Shape "sphere"\nWorldEnd')
+    t = s.desc.textures[s.desc.materials[1].u0[0]]
+    assert t.type == abi.TEXTURE_SOLID and [t.v0[0], t.v0[1], t.v0[2]] == [np.float32(.7), np.float32(.2), np.float32(.2)]
+
+
+def test_world(hip_lib):  # test_world: LightSource "infinite" "rgb L" [.4 .45 .5]
+    s = parse('WorldBegin\nLightSource "infinite" "rgb L" [.4 .45 .5]\nWorldEnd')
+    assert list(s.desc.uniform.background_color) == [np.float32(.4), np.float32(.45), np.float32(.5), 0.0]
+
+
+SPHERE_SCENE = '''
+LookAt 3 4 1.5  # eye
+       .0 .0 0  # look at point
+       0 0 1    # up vector
+Camera "perspective" "float fov" 45
+
+WorldBegin
+
+# uniform blue-ish illumination from all directions
+LightSource "infinite" "rgb L" [.4 .45 .5]
+
+AttributeBegin
+  Material "matte" "rgb Kd" [ .7 .2 .2 ]
+  Shape "sphere" "float radius" 1
+AttributeEnd
+
+WorldEnd
+        '''
+
+
+def test_world_statement(hip_lib):  # test_world_statement: the WorldBegin .. WorldEnd block of the sphere scene
+    s = parse(SPHERE_SCENE[SPHERE_SCENE.index("WorldBegin"):])
+    assert s.desc.n_instances == 1 and s.desc.instances[0].shape == abi.SHAPE_SPHERE
+
+
+def test_sphere(hip_lib):  # test_sphere: sample_scenes/sphere.pbrt
+    s = parse(SPHERE_SCENE)
+    d = s.desc
+    assert (d.xresolution, d.yresolution) == (640, 480) and s.film_filename == "out.png"  # Film defaults
+    assert d.n_materials == 2 and d.materials[1].type == abi.MATERIAL_MATTE
+    assert d.instances[0].material_index == 1 and d.instances[0].area_light_index == 0
+    # camera at (3, 4, 1.5) looking at the origin
+    c2w = np.array(d.uniform.camera_to_world[:]).reshape(4, 4).T
+    np.testing.assert_allclose(c2w[:3, 3], [3, 4, 1.5], atol=1e-5)
+    fwd = c2w[:3, 2]
+    np.testing.assert_allclose(fwd, -np.array([3, 4, 1.5]) / np.linalg.norm([3, 4, 1.5]), atol=1e-6)
+    info = api.pack_info(s)
+    assert info.n_spheres == 1 and info.features & 16  # non-black background
+
+
+# ---- Scene::create semantics ----------------------------------------------------------------------------
+def test_cornell_roundtrip_equals_synthetic(hip_lib):
+    """scenes.cornell_box() serialised to pbrt text and loaded back produces byte-identical tables."""
+    syn = scenes.cornell_box(1024, 1024)
+    a = loader.desc_tables(syn.to_desc().desc)
+    b = parse(loader.scene_to_pbrt(syn)).tables()
+    assert a["res"] == b["res"] and a["integrator"] == b["integrator"]
+    for k in ("instances", "materials", "textures", "area_lights", "lights"):
+        assert np.array_equal(a[k], b[k]), k
+    for (va, ia), (vb, ib) in zip(a["meshes"], b["meshes"]):
+        assert np.array_equal(va, vb) and np.array_equal(ia, ib)
+    np.testing.assert_allclose(a["uniform"], b["uniform"], rtol=2e-6, atol=1e-7)
+
+
+def test_attribute_and_transform_scopes(hip_lib):
+    s = parse('''WorldBegin
+      Material "matte" "rgb Kd" [1 0 0]
+      TransformBegin
+        Translate 1 2 3
+        Material "matte" "rgb Kd" [0 1 0]     # Q10: TransformBegin is an Attribute scope -> does not leak
+        Shape "sphere"
+      TransformEnd
+      Shape "sphere" "float radius" 2
+      AttributeBegin
+        Scale 2 2 2
+        AreaLightSource "diffuse" "rgb L" [5 5 5]
+        Shape "sphere"
+      AttributeEnd
+      Shape "sphere"
+    WorldEnd''')
+    d = s.desc
+    m = [d.instances[i].material_index for i in range(4)]
+    assert m == [2, 1, 1, 1]
+    assert list(d.instances[0].matrix[9:12]) == [1, 2, 3] and list(d.instances[1].matrix[9:12]) == [0, 0, 0]
+    assert d.instances[1].matrix[0] == 2 and d.instances[2].matrix[0] == 2 and d.instances[3].matrix[0] == 1
+    assert [d.instances[i].area_light_index for i in range(4)] == [0, 0, 1, 0]
+
+
+def test_object_instancing_composes_object_times_ctm(hip_lib):
+    s = parse('''WorldBegin
+      ObjectBegin "thing"
+        Translate 1 0 0
+        Shape "sphere"
+      ObjectEnd
+      Scale 2 2 2
+      ObjectInstance "thing"
+      ObjectInstance "thing"
+    WorldEnd''')
+    d = s.desc
+    assert d.n_instances == 2  # the definition itself is not rendered (scene.rs:279-288)
+    # ObjectBegin is not an attribute scope in rene (scene.rs:279-281 reuses `state`), so the Translate
+    # leaks: CTM = T(1) S(2) at the ObjectInstance; object.matrix * CTM (scene.rs:296) = T(1) T(1) S(2)
+    assert list(d.instances[0].matrix[:]) == [2, 0, 0, 0, 2, 0, 0, 0, 2, 2, 0, 0]
+
+
+def test_material_defaults_and_quirks(hip_lib):
+    s = parse('''WorldBegin
+      Material "mirror" "rgb Kr" [0.1 0.1 0.1]
+      Material "plastic"
+      Material "metal" "float roughness" 0.2
+      Material "substrate" "float uroughness" 0.1 "float vroughness" 0.3 "bool remaproughness" "false"
+      Material "uber" "float eta" 1.3
+      Material "glass"
+      Material ""
+    WorldEnd''')
+    d = s.desc
+    tex = lambda i: [round(float(x), 6) for x in d.textures[i].v0[:3]]
+    assert d.materials[1].type == abi.MATERIAL_MIRROR and tex(d.materials[1].u0[0]) == [0.9, 0.9, 0.9]  # reads Kd
+    pl = d.materials[2]
+    assert pl.type == abi.MATERIAL_PLASTIC and pl.u0[2] == 1 and pl.u1[2] == 0  # Q8: flag lives in u0.z
+    me = d.materials[3]
+    assert me.type == abi.MATERIAL_METAL and tex(me.u0[2]) == [0.2] * 3 and tex(me.u0[3]) == [0.2] * 3 and me.u1[0] == 1
+    assert tex(me.u0[0]) == [0.199991, 0.922085, 1.099876]
+    su = d.materials[4]
+    assert tex(su.u0[2]) == [0.1] * 3 and tex(su.u0[3]) == [0.3] * 3 and su.u1[0] == 0 and tex(su.u0[0]) == [0.5] * 3
+    ub = d.materials[5]
+    assert ub.type == abi.MATERIAL_UBER and abs(ub.v0[0] - 1.3) < 1e-6 and tex(ub.u1[0]) == [1.0] * 3
+    assert d.materials[6].type == abi.MATERIAL_GLASS and d.materials[6].v0[0] == 1.5
+    assert d.materials[7].type == abi.MATERIAL_NONE
+
+
+def test_textures_lights_integrator(hip_lib):
+    s = parse('''Integrator "bdpt"
+    Film "image" "integer xresolution" [300] "integer yresolution" [400] "string filename" "x.exr"
+    WorldBegin
+      Texture "checks" "spectrum" "checkerboard" "float uscale" [8] "float vscale" [8] "rgb tex1" [.1 .1 .1] "rgb tex2" [.8 .8 .8]
+      Texture "c" "float" "constant" "float value" 0.25
+      Texture "sc" "spectrum" "scale" "texture tex1" "checks" "texture tex2" "c"
+      Material "matte" "texture Kd" "checks"
+      LightSource "distant" "point from" [0 0 2] "rgb L" [3 3 3]
+    WorldEnd''')
+    d = s.desc
+    assert d.integrator == abi.INTEGRATOR_VOLPATH  # Q7: unknown integrators select volpath
+    with pytest.raises(api.ReneError) as e:
+        api.pack_info(s)
+    assert e.value.code == -4
+    ck = d.textures[3]
+    assert ck.type == abi.TEXTURE_CHECKERBOARD and (ck.u0[0], ck.u0[1]) == (1, 2) and (ck.v0[0], ck.v0[1]) == (8, 8)
+    assert d.textures[4].type == abi.TEXTURE_SOLID and d.textures[4].v0[0] == 0.25
+    assert d.textures[5].type == abi.TEXTURE_SCALE and (d.textures[5].u0[0], d.textures[5].u0[1]) == (3, 4)
+    assert d.materials[1].u0[0] == 3
+    assert list(d.lights[0].v0[:3]) == [0, 0, 1] and list(d.lights[0].v1[:3]) == [3, 3, 3]
+    assert (d.xresolution, d.yresolution) == (300, 400)
+    # portrait fix-up of the fov (scene.rs:156-162): projection_inv[0] = aspect * tan(fov'/2)
+    pinv = np.array(d.uniform.projection_inv[:]).reshape(4, 4).T
+    assert pinv[1, 1] == pytest.approx(np.tan(np.pi / 4) / 300 * 400, rel=1e-5)
+
+
+def test_errors(hip_lib):
+    cases = {
+        'WorldBegin\nShape "cone"\nWorldEnd': -2,
+        'WorldBegin\nNamedMaterial "nope"\nWorldEnd': -2,
+        'WorldBegin\nObjectInstance "nope"\nWorldEnd': -2,
+        'WorldBegin\nMaterial "matte" "texture Kd" "nope"\nWorldEnd': -2,
+        'WorldBegin\nShape "sphere" "float radius" [1 2]\nWorldEnd': -2,
+        'WorldBegin\nShape "sphere"': -7,
+        'Camera "perspective" "float fov" abc' + WORLD: -7,
+        'Bogus 1 2 3': -7,
+        'WorldBegin\nMaterial "matte" "rgb Kd" [1 2]\nWorldEnd': -7,
+        'WorldBegin\nMaterial "matte" "blackbody Kd" [3000 1]\nWorldEnd': -4,
+        'WorldBegin\nShape "loopsubdiv" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd': -4,
+        'WorldBegin\nShape "plymesh" "string filename" "missing.ply"\nWorldEnd': -6,
+        'Include "missing.pbrt"': -6,
+    }
+    for src, code in cases.items():
+        with pytest.raises(api.ReneError) as e:
+            parse(src, "/nonexistent")
+        assert e.value.code == code, (src, e.value)
+    with pytest.raises(api.ReneError) as e:
+        loader.load_pbrt("/nonexistent/scene.pbrt")
+    assert e.value.code == -6
+
+
+def test_include_ply_pfm(tmp_path, hip_lib):
+    import struct
+    # binary little-endian PLY with normals + uv and a quad face; ascii PLY; PFM env map; Include
+    verts = [(0, 0, 0, 0, 0, 1, 0, 0), (1, 0, 0, 0, 0, 1, 1, 0), (1, 1, 0, 0, 0, 1, 1, 1), (0, 1, 0, 0, 0, 1, 0, 1)]
+    hdr = ("ply\nformat binary_little_endian 1.0\nelement vertex 4\nproperty float x\nproperty float y\nproperty float z\n"
+           "property float nx\nproperty float ny\nproperty float nz\nproperty float u\nproperty float v\n"
+           "element face 1\nproperty list uchar int vertex_indices\nend_header\n").encode()
+    body = b"".join(struct.pack("<8f", *v) for v in verts) + struct.pack("<B4i", 4, 0, 1, 2, 3)
+    (tmp_path / "quad.ply").write_bytes(hdr + body)
+    (tmp_path / "tri.ply").write_text("ply\nformat ascii 1.0\nelement vertex 3\nproperty float x\nproperty float y\n"
+                                      "property float z\nelement face 1\nproperty list uchar uint vertex_indices\n"
+                                      "end_header\n0 0 0\n1 0 0\n0 1 0\n3 0 1 2\n")
+    px = np.arange(2 * 3 * 3, dtype=np.float32).reshape(2, 3, 3)  # h=2, w=3; PFM stores the bottom row first
+    (tmp_path / "env.pfm").write_bytes(b"PF\n3 2\n-1.0\n" + px.tobytes())
+    (tmp_path / "geo.pbrt").write_text('Shape "plymesh" "string filename" "quad.ply"\nShape "plymesh" "string filename" [ "tri.ply" ]\n')
+    (tmp_path / "scene.pbrt").write_text('WorldBegin\nMaterial "matte"\nInclude "geo.pbrt"\n'
+                                         'LightSource "infinite" "string mapname" "env.pfm"\nWorldEnd\n')
+    s = loader.load_pbrt(str(tmp_path / "scene.pbrt"))
+    t = s.tables()
+    (v0, i0), (v1, i1) = t["meshes"]
+    assert i0.tolist() == [0, 1, 2, 0, 2, 3] and i1.tolist() == [0, 1, 2]  # quad split, intermediate_scene.rs:741-744
+    np.testing.assert_array_equal(v0, np.array(verts, np.float32))
+    assert (v1[:, 3:] == 0).all()  # no normals / uv in the file -> zeros -> geometric normal on the device
+    d = s.desc
+    assert d.n_images == 1 and d.images[0].width == 3 and d.images[0].height == 2
+    img = np.frombuffer(C.string_at(d.images[0].rgba, 2 * 3 * 4 * 4), np.float32).reshape(2, 3, 4)
+    np.testing.assert_array_equal(img[..., :3], px[::-1])  # top row first in memory
+    assert d.uniform.background_texture == d.n_textures - 1 and list(d.uniform.background_color[:3]) == [1, 1, 1]
+
+
+@pytest.mark.reference
+@pytest.mark.skipif(not have_reference(), reason="needs /root/reference/sample_scenes")
+def test_reference_sample_scenes(hip_lib):
+    sc = os.path.join(REFERENCE, "sample_scenes")
+    a = loader.load_pbrt(os.path.join(sc, "cornell-box", "scene.pbrt")).tables()
+    b = loader.desc_tables(scenes.cornell_box(1024, 1024).to_desc().desc)
+    for k in ("instances", "materials", "textures", "area_lights", "lights"):
+        assert np.array_equal(a[k], b[k]), k
+    for (va, ia), (vb, ib) in zip(a["meshes"], b["meshes"]):
+        assert np.array_equal(va, vb) and np.array_equal(ia, ib)
+    np.testing.assert_allclose(a["uniform"], b["uniform"], rtol=2e-6, atol=1e-7)
+    v = loader.load_pbrt(os.path.join(sc, "veach-mis", "scene.pbrt")).tables()
+    w = loader.desc_tables(scenes.veach_mis(1280, 720).to_desc().desc)
+    for k in ("instances", "materials", "textures", "area_lights"):
+        assert np.array_equal(v[k], w[k]), k
+    for (va, ia), (vb, ib) in zip(v["meshes"], w["meshes"]):
+        assert np.array_equal(va, vb) and np.array_equal(ia, ib)
+    for name in ("cube.pbrt", "sphere.pbrt"):
+        s = loader.load_pbrt(os.path.join(sc, name))
+        assert api.pack_info(s).n_instances >= 1
+    for name, code in (("current.pbrt", -4), ("dragon/scene.pbrt", -6), ("teapot/scene.pbrt", -6)):
+        with pytest.raises(api.ReneError) as e:  # blackbody L / missing meshes / missing envmap (.MISSING_LARGE_BLOBS)
+            loader.load_pbrt(os.path.join(sc, name))
+        assert e.value.code == code, name
