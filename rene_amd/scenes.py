@@ -186,3 +186,73 @@ def material_zoo(xres: int = 96, yres: int = 64) -> Scene:
     s.add_mesh_instance(s.instances[ci].mesh_index, mats[4],
                         ctm=glam.mul(glam.from_translation((-4.2, 0.0, 2.4)), glam.from_scale((-0.4, 0.6, 0.4))))
     return s
+
+
+# ---------------------------------------------------------------------------------------------------
+# dragon-class (BASELINE config 4): the real dragon cannot be rendered here (4 of its meshes are
+# absent from the reference checkout, .MISSING_LARGE_BLOBS), so SURVEY.md section 8d defines a
+# stand-in of the same character: ~870 k triangles, all Matte, one distant light, NO area emitter
+# (lights_len = 1, emit_object_len = 0 -> the plain-BSDF branch, lib.rs:325-337).
+# ---------------------------------------------------------------------------------------------------
+def _value_noise(p: np.ndarray, seed: int, octaves: int = 5) -> np.ndarray:
+    """Deterministic lattice value noise on points p (n, 3), summed over octaves, in [-1, 1]."""
+    def hash01(ix, iy, iz, s):
+        h = (ix.astype(np.uint64) * np.uint64(73856093)) ^ (iy.astype(np.uint64) * np.uint64(19349663)) \
+            ^ (iz.astype(np.uint64) * np.uint64(83492791)) ^ np.uint64(s * 2654435761 % (1 << 32))
+        h = (h ^ (h >> np.uint64(13))) * np.uint64(1274126177) % np.uint64(1 << 32)
+        return (h % np.uint64(1 << 24)).astype(np.float64) / float(1 << 24)
+
+    out = np.zeros(p.shape[0], np.float64)
+    amp, freq = 1.0, 2.0
+    for o in range(octaves):
+        q = p.astype(np.float64) * freq + 100.0
+        i0 = np.floor(q).astype(np.int64)
+        f = q - i0
+        f = f * f * (3 - 2 * f)
+        acc = np.zeros(p.shape[0], np.float64)
+        for dx in (0, 1):
+            for dy in (0, 1):
+                for dz in (0, 1):
+                    w = (f[:, 0] if dx else 1 - f[:, 0]) * (f[:, 1] if dy else 1 - f[:, 1]) * (f[:, 2] if dz else 1 - f[:, 2])
+                    acc += w * hash01(i0[:, 0] + dx, i0[:, 1] + dy, i0[:, 2] + dz, seed + o)
+        out += amp * (2 * acc - 1)
+        amp *= 0.5
+        freq *= 2.0
+    return out / 1.9375
+
+
+def displaced_sphere(n_lat: int = 640, n_lon: int = 680, radius: float = 0.42, amplitude: float = 0.11,
+                     seed: int = 7) -> TriangleMesh:
+    """Latitude/longitude sphere (poles trimmed), radially displaced by value noise:
+    2 * n_lat * n_lon triangles (870 400 by default), no vertex normals (flat shading)."""
+    th = np.linspace(0.02, np.pi - 0.02, n_lat + 1)
+    ph = np.linspace(0.0, 2 * np.pi, n_lon + 1)
+    T, P = np.meshgrid(th, ph, indexing="ij")
+    d = np.stack([np.sin(T) * np.cos(P), np.cos(T), np.sin(T) * np.sin(P)], axis=-1).reshape(-1, 3)
+    d[np.isclose(P.reshape(-1), 2 * np.pi)] = d[np.isclose(P.reshape(-1), 0.0)]  # close the seam exactly
+    r = radius * (1.0 + amplitude * _value_noise(d, seed))
+    pos = (d * r[:, None]).astype(F32)
+    i = np.arange(n_lat)[:, None] * (n_lon + 1) + np.arange(n_lon)[None, :]
+    a, b, c, e = i, i + 1, i + n_lon + 1, i + n_lon + 2
+    idx = np.stack([a, c, b, b, c, e], axis=-1).reshape(-1).astype(np.uint32)
+    return TriangleMesh.from_arrays(pos, idx)
+
+
+def dragon_class(xres: int = 1920, yres: int = 1080, n_lat: int = 640, n_lon: int = 680) -> Scene:
+    """Cornell room (walls + tall box) whose short box is replaced by the displaced sphere; the quad
+    emitter is removed and the dragon scene's distant light added (dragon/scene.pbrt:44)."""
+    s = Scene.new()
+    s.film.filename = "dragon-class.png"
+    s.set_camera(glam.from_cols_array(CORNELL_WORLD_TO_CAMERA), CORNELL_FOV_DEG * 1.0, xres, yres)
+    white = s.add_matte((0.725, 0.71, 0.68))
+    red, green = s.add_matte((0.63, 0.065, 0.05)), s.add_matte((0.14, 0.45, 0.091))
+    clay = s.add_matte((0.79311, 0.79311, 0.79311))  # "Dragon" Kd, dragon/scene.pbrt:11
+    s.add_triangle_mesh(_quad([-1, 1.74846e-07, -1, -1, 1.74846e-07, 1, 1, -1.74846e-07, 1,
+                               1, -1.74846e-07, -1], (4.37114e-08, 1, 1.91069e-15)), white)
+    s.add_triangle_mesh(_quad([-1, 0, -1, -1, 2, -1, 1, 2, -1, 1, 0, -1], (8.74228e-08, -4.37114e-08, -1)), white)
+    s.add_triangle_mesh(_quad([1, 0, -1, 1, 2, -1, 1, 2, 1, 1, 0, 1], (1, -4.37114e-08, 1.31134e-07)), green)
+    s.add_triangle_mesh(_quad([-1, 0, 1, -1, 2, 1, -1, 2, -1, -1, 0, -1], (-1, -4.37114e-08, -4.37114e-08)), red)
+    s.add_triangle_mesh(_box(_TALL_BOX_P, _TALL_BOX_N), white)
+    s.add_triangle_mesh(displaced_sphere(n_lat, n_lon), clay, ctm=glam.from_translation((0.33, 0.48, 0.35)))
+    s.add_light_distant((-0.18862, 0.692312, 0.69651), (0.0, 0.0, 0.0), (8.0, 8.0, 8.0))
+    return s

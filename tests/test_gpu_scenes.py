@@ -78,3 +78,27 @@ def test_cornell_with_distant_light_and_no_emitter(oracle_mod):
     s.add_light_distant((-0.18862, 0.692312, 0.69651), (0, 0, 0), (8, 8, 8))  # dragon/scene.pbrt:44
     sg, so = _compare(s, 8, oracle_mod, frac=1e-3, relmse=1e-4, ctol=1e-4)
     assert sg["rays_emitter"] == 0 and sg["rays_shadow"] == sg["hits"]
+
+
+@pytest.mark.parametrize("n_lat,n_lon,res", [(48, 52, (160, 90)), (640, 680, (240, 136))])
+def test_dragon_class_bvh_path(oracle_mod, n_lat, n_lon, res):
+    """BASELINE config 4 stand-in: a displaced sphere of 2*n_lat*n_lon triangles (870 400 at
+    full size) in the Cornell room, Matte, one distant light, no emitter -> deep BVH traversal, shadow
+    rays with any-hit early-out, plain BSDF sampling."""
+    s = scenes.dragon_class(res[0], res[1], n_lat, n_lon)
+    info = api.pack_info(s)
+    assert info.n_triangles == 2 * n_lat * n_lon + 20 and not (info.features & 64)  # too big for the item loop
+    sg, so = _compare(s, 4, oracle_mod, frac=2e-3, relmse=1e-4, ctol=5e-4)
+    assert sg["rays_emitter"] == 0 and sg["rays_shadow"] == sg["hits"]
+    # traversal alone, against the oracle's two-level BVH
+    o = oracle_mod.Oracle(s)
+    rng = np.random.default_rng(4)
+    n = 20000
+    org = np.tile(np.array([[0, 1, 6.8]], np.float32), (n, 1))
+    d = np.stack([rng.uniform(-.25, .25, n), rng.uniform(-.17, .17, n), -np.ones(n)], 1)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    with api.Renderer(s) as r:
+        hg, ho = r.trace(org, d), o.trace(org, d)
+    tie = np.abs(hg["t"] - ho["t"]) <= 2e-5 * (1 + np.abs(ho["t"]))
+    bad = ((hg["t"] < 0) != (ho["t"] < 0)) | ((ho["t"] >= 0) & (hg["primitive"] != ho["primitive"]) & ~tie)
+    assert bad.sum() <= 5, bad.sum()
