@@ -75,9 +75,13 @@ def main():
     n_gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    # Normally one rank per GPU over RCCL.  RENE_DIST_BACKEND=gloo lets several ranks share one GPU
+    # (a rehearsal of the N > 1 code path on a 1-GPU box; RCCL refuses two ranks on one device).
+    backend = os.environ.get("RENE_DIST_BACKEND", "nccl")
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     if world > 1:
-        rdist.init_process_group("nccl")
+        rdist.init_process_group(backend)
         import torch.distributed as dist
 
     K, Wm = max(1, args.steps), max(0, args.warmup)
@@ -97,10 +101,13 @@ def main():
         cst = rc.stats()
     bytes_per_ray = abi.algorithmic_bytes(cst) / max(1, cst.rays)
 
-    # ---- warmup, then a clean accumulation image ----
+    # ---- warmup (kernel + the collective: RCCL sets its rings up lazily), then a clean image ----
     for k in range(Wm):
         r.render(k * F, F)
     r.sync()
+    if world > 1:
+        rdist.reduce_framebuffer(fb, dst=0)
+        torch.cuda.synchronize()
     r.reset()
     fb.zero_()
 

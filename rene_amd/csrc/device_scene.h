@@ -179,6 +179,9 @@ struct RenderParams {
   uint32_t shard_rank, shard_count;  // tile sharding (shard_count == 1: all tiles)
   uint32_t tiles_x, n_tiles;
   uint32_t flags;
+  uint32_t two_level;      // 1: every pixel is cut into a long and a short work item (ordered hand-off)
+  uint32_t epoch;          // launch number (>= 1): value a long item publishes in item_done[]
+  uint32_t* item_done;     // [n_work] per-pixel hand-off flags
 };
 
 }  // namespace rene

@@ -999,18 +999,24 @@ RENE_DEV f3 emit_sample(const SceneView& S, uint32_t obj, Pcg& rng) {
 // =================================================================================================
 RENE_DEV uint32_t lane_id() { return __lane_id(); }
 
-// wave-aggregated fetch of the next work id: one atomic per wave per fetch round
-RENE_DEV uint32_t fetch_work(uint32_t* counter, bool need) {
-  unsigned long long mask = __ballot(need);
-  if (mask == 0ull) return 0xffffffffu;
-  uint32_t lane = lane_id();
-  int leader = __ffsll((long long)mask) - 1;
-  uint32_t base = 0;
-  if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-  base = __shfl(base, leader);
-  uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-  return need ? base + rank : 0xffffffffu;
+// ---- accumulation-image records: 16-byte RGBA, always accessed write-through / L1-bypassing ("sc1") so
+// that a pixel's running sums can be handed from one lane to another lane on another CU/XCD inside a
+// launch (cdna_hip_programming.md Guideline 16: payload stored sc1 and drained, flag = agent-scope
+// atomic, every load of the handed-off bytes an sc1 load; no plain load of the image exists in this kernel)
+// (12-byte accesses: the alpha channel is never read or written, like the reference, lib.rs:170)
+typedef float v3f __attribute__((ext_vector_type(3)));
+RENE_DEV f3 fb_load(const float* p) {
+  v3f v;
+  asm volatile("global_load_dwordx3 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return mk3(v.x, v.y, v.z);
 }
+RENE_DEV void fb_store(float* p, f3 a) {
+  v3f v = {a.x, a.y, a.z};
+  asm volatile("global_store_dwordx3 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+}
+RENE_DEV void fb_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+constexpr uint32_t WORK_BATCH = 128;  // work ids a wave takes per global atomic
 
 RENE_DEV unsigned long long wave_sum(uint32_t v) {
   unsigned long long s = v;
@@ -1031,8 +1037,13 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneView S, RenderParams
   const uint32_t W = S.width, H = S.height;
   const float tmin = 0.001f, tmax = 100000.0f;  // lib.rs:182-183
 
-  // pixel state
+  // work-item state: one item = (pixel, frame range).  A launch of F >= 4 frames cuts every pixel into
+  // a long item (frames [0, F - F/4)) and a short one (the rest); all long items are handed out before
+  // any short one, so the end of the launch is balanced at a quarter of a pixel's cost.  The short
+  // item continues the running sums its long item committed (same summation order as one lane doing
+  // all F frames), synchronised through P.item_done[] with the sc1 hand-off described above.
   uint32_t work = 0xffffffffu, px = 0, py = 0, frame = 0;
+  bool waiting = false, second = false;
   f3 acc0 = splat(0.0f), acc1 = splat(0.0f), acc2 = splat(0.0f);
   // path state
   bool active = false, done = false;
@@ -1041,56 +1052,96 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneView S, RenderParams
   int depth = 0;
 
   const size_t layer_stride = (size_t)W * H * 4;
+  const uint32_t F = P.n_frames;
+  const bool two_level = P.two_level != 0;
+  const uint32_t F0 = two_level ? F - F / 4u : F;
+  const uint32_t total_items = two_level ? 2u * P.n_work : P.n_work;
+  // wave-uniform batch of work ids
+  uint32_t batch_next = 0, batch_end = 0;
+  bool exhausted = false;
+
+  uint32_t wait_iters = 0;
 
   for (;;) {
-    // ---- pixel bookkeeping ----------------------------------------------------------------------
-    bool finished_pixel = !active && work != 0xffffffffu && frame == P.n_frames;
-    if (finished_pixel) {
+    // ---- item bookkeeping --------------------------------------------------------------------------
+    const uint32_t frame_end = second ? F : F0;
+    bool finished = !active && !waiting && work != 0xffffffffu && frame == frame_end;
+    if (finished) {
       float* p = P.framebuffer + ((size_t)(H - 1 - py) * W + px) * 4;  // add_image target, lib.rs:166
-      p[0] = acc0.x; p[1] = acc0.y; p[2] = acc0.z;
       if (AOV) {
-        float* p1 = p + layer_stride;
-        p1[0] = acc1.x; p1[1] = acc1.y; p1[2] = acc1.z;
-        float* p2 = p + 2 * layer_stride;
-        p2[0] = acc2.x; p2[1] = acc2.y; p2[2] = acc2.z;
+        fb_store(p + layer_stride, acc1);
+        fb_store(p + 2 * layer_stride, acc2);
+      }
+      fb_store(p, acc0);
+      if (two_level && !second) {
+        fb_drain();  // the sc1 stores have reached memory before the flag can be seen
+        __hip_atomic_store(P.item_done + work, P.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       work = 0xffffffffu;
     }
-    bool need = !done && !active && work == 0xffffffffu;
+    bool need = !done && work == 0xffffffffu;
     if (__any(need)) {
-      uint32_t w = fetch_work(P.work_counter, need);
-      if (need) {
-        if (w >= P.n_work) {
-          done = true;
+      if (batch_next >= batch_end && !exhausted) {  // wave-uniform: refill with one global atomic
+        uint32_t base = 0;
+        if (lane_id() == 0) base = atomicAdd(P.work_counter, WORK_BATCH);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (base >= total_items) {
+          exhausted = true;
         } else {
-          // work id -> pixel: owned 32x32 tiles, 8x8 micro-tiles inside (a wave = one micro-tile)
-          uint32_t k = w >> 10, r = w & 1023u;
-          uint32_t tile = P.shard_rank + k * P.shard_count;
-          uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
-          uint32_t sub = r >> 6, l = r & 63u;
-          uint32_t x = tx * RENE_TILE_SIZE + (sub & 3u) * 8u + (l & 7u);
-          uint32_t yi = ty * RENE_TILE_SIZE + (sub >> 2) * 8u + (l >> 3);  // image row, top first
-          if (x < W && yi < H) {
-            work = w;
-            px = x;
-            py = H - 1 - yi;  // launch_id.y
-            frame = 0;
-            const float* p = P.framebuffer + ((size_t)yi * W + x) * 4;
-            acc0 = mk3(p[0], p[1], p[2]);
-            if (AOV) {
-              const float* p1 = p + layer_stride;
-              acc1 = mk3(p1[0], p1[1], p1[2]);
-              const float* p2 = p + 2 * layer_stride;
-              acc2 = mk3(p2[0], p2[1], p2[2]);
-            }
-          }
+          batch_next = base;
+          batch_end = base + WORK_BATCH < total_items ? base + WORK_BATCH : total_items;
         }
+      }
+      unsigned long long mask = __ballot(need);
+      uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane_id()) - 1ull));
+      uint32_t id = batch_next + rank;
+      bool got = need && !exhausted && id < batch_end;
+      uint32_t taken = (uint32_t)__popcll(mask);
+      batch_next = batch_next + taken < batch_end ? batch_next + taken : batch_end;
+      if (need && exhausted) done = true;
+      if (got) {
+        bool sec = id >= P.n_work;
+        uint32_t w = sec ? id - P.n_work : id;
+        // item -> pixel: owned 32x32 tiles, 8x8 micro-tiles inside (a wave starts on one micro-tile)
+        uint32_t k = w >> 10, r = w & 1023u;
+        uint32_t tile = P.shard_rank + k * P.shard_count;
+        uint32_t tx = tile % P.tiles_x, ty = tile / P.tiles_x;
+        uint32_t sub = r >> 6, l = r & 63u;
+        uint32_t x = tx * RENE_TILE_SIZE + (sub & 3u) * 8u + (l & 7u);
+        uint32_t yi = ty * RENE_TILE_SIZE + (sub >> 2) * 8u + (l >> 3);  // image row, top first
+        if (x < W && yi < H) {
+          work = id;
+          second = sec;
+          px = x;
+          py = H - 1 - yi;  // launch_id.y
+          frame = sec ? F0 : 0u;
+          waiting = true;  // sums are loaded below (a short item first waits for its long item)
+          wait_iters = 0;
+        }
+      }
+    }
+    if (waiting) {
+      bool ready = !second || __hip_atomic_load(P.item_done + (work - P.n_work), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == P.epoch;
+      if (!ready && ++wait_iters > (1u << 22)) {
+        // safety net so that every wave can leave: a long item always makes progress, so this bound is
+        // never reached; if it were, the host reports RENE_ERR_DEVICE
+        atomicAdd(&P.counters[8], 1ull);
+        ready = true;
+      }
+      if (ready) {
+        const float* p = P.framebuffer + ((size_t)(H - 1 - py) * W + px) * 4;
+        acc0 = fb_load(p);
+        if (AOV) {
+          acc1 = fb_load(p + layer_stride);
+          acc2 = fb_load(p + 2 * layer_stride);
+        }
+        waiting = false;
       }
     }
     if (__all(done)) break;
 
     // ---- ray generation, lib.rs:174-189 -----------------------------------------------------------
-    if (!active && work != 0xffffffffu && frame < P.n_frames) {
+    if (!active && !waiting && work != 0xffffffffu && frame < (second ? F : F0)) {
       uint32_t seed = P.seeds[frame];
       frame++;
       lc.paths++;

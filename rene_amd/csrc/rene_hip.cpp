@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <memory>
@@ -69,6 +70,8 @@ struct rene_ctx {
   bool own_fb = false;
   size_t fb_floats = 0;
   uint32_t* d_work_counter = nullptr;
+  uint32_t* d_item_done = nullptr;
+  uint32_t epoch = 0;
   unsigned long long* d_counters = nullptr;
   // per-launch resources that must outlive the asynchronous launch
   struct Pending {
@@ -253,6 +256,10 @@ int rene_create(const rene_scene_desc* scene, const rene_opts* opts, rene_ctx** 
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, o.device));
   c->cfg.grid = (uint32_t)prop.multiProcessorCount * 8u;  // persistent launch; surplus blocks find no work
+  if (const char* e = std::getenv("RENE_BLOCKS_PER_CU")) {  // tuning knob (experiments only)
+    int b = std::atoi(e);
+    if (b > 0 && b <= 64) c->cfg.grid = (uint32_t)prop.multiProcessorCount * (uint32_t)b;
+  }
 
   c->tiles_x = (ps.width + RENE_TILE_SIZE - 1) / RENE_TILE_SIZE;
   uint32_t tiles_y = (ps.height + RENE_TILE_SIZE - 1) / RENE_TILE_SIZE;
@@ -274,6 +281,8 @@ int rene_create(const rene_scene_desc* scene, const rene_opts* opts, rene_ctx** 
   }
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_work_counter), sizeof(uint32_t)));
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_counters), 16 * sizeof(unsigned long long)));
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_item_done), std::max<size_t>(1, c->n_work) * sizeof(uint32_t)));
+  HIP_TRY(hipMemsetAsync(c->d_item_done, 0, std::max<size_t>(1, c->n_work) * sizeof(uint32_t), c->stream));
   HIP_TRY(hipMemsetAsync(c->fb, 0, c->fb_floats * sizeof(float), c->stream));  // main.rs:1229-1237
   HIP_TRY(hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -296,6 +305,7 @@ void rene_destroy(rene_ctx* c) {
   if (c->own_fb && c->fb) hipFree(c->fb);
   if (c->d_work_counter) hipFree(c->d_work_counter);
   if (c->d_counters) hipFree(c->d_counters);
+  if (c->d_item_done) hipFree(c->d_item_done);
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
   delete c;
 }
@@ -342,6 +352,13 @@ int rene_render(rene_ctx* c, uint32_t first_frame, uint32_t n_frames) {
   P.tiles_x = c->tiles_x;
   P.n_tiles = c->n_tiles;
   P.flags = c->opts.flags;
+  P.two_level = (P.n_frames >= 4 && !(c->opts.flags & RENE_FLAG_SINGLE_LEVEL)) ? 1u : 0u;
+  if (++c->epoch == 0) {  // the flag array never needs clearing between launches unless the epoch wraps
+    hipMemsetAsync(c->d_item_done, 0, std::max<size_t>(1, c->n_work) * sizeof(uint32_t), c->stream);
+    c->epoch = 1;
+  }
+  P.epoch = c->epoch;
+  P.item_done = c->d_item_done;
   rene::LaunchConfig cfg = c->cfg;
   uint32_t blocks_needed = (c->n_work + rene::render_block_size() - 1) / rene::render_block_size();
   cfg.grid = std::max(1u, std::min(cfg.grid, blocks_needed));
@@ -412,8 +429,9 @@ int rene_get_stats(rene_ctx* c, rene_stats* out) {
   HIP_TRY(hipSetDevice(c->device));
   int rc = c->drain();
   if (rc != RENE_OK) return rc;
-  unsigned long long h[8];
+  unsigned long long h[9];
   HIP_TRY(hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
+  if (h[8] != 0) return fail(RENE_ERR_DEVICE, "a work-item hand-off timed out inside the render kernel (results invalid)");
   std::memset(out, 0, sizeof(*out));
   out->rays_closest = h[0];
   out->rays_shadow = h[1];

@@ -183,3 +183,20 @@ def test_create_errors_on_gpu():
     with pytest.raises(api.ReneError) as e:
         api.Renderer(s, shard_rank=3, shard_count=2)
     assert e.value.code == -1
+
+
+@pytest.mark.parametrize("res,frames", [((1024, 1024), 64), ((160, 96), 7), ((96, 64), 4), ((64, 64), 3), ((200, 120), 33)])
+def test_long_short_work_items_are_bit_identical_to_one_item_per_pixel(res, frames):
+    """A launch cuts each pixel into a long and a short work item whose running sums are handed from
+    lane to lane through the accumulation image (sc1 stores + agent-scope flag).  Any lost or stale
+    hand-off would change the image: it must equal the one-item-per-pixel render bit for bit."""
+    s = scenes.cornell_box(*res)
+    with api.Renderer(s) as a, api.Renderer(s, flags=abi.FLAG_SINGLE_LEVEL) as b:
+        for r in (a, b):
+            r.render(0, frames)
+            r.render(frames, frames)  # a second launch continues the sums (epoch 2)
+        for layer in range(3):
+            assert np.array_equal(a.download(layer, 4), b.download(layer, 4)), layer
+        sa, sb = a.stats().as_dict(), b.stats().as_dict()
+        for k in ("rays_closest", "rays_emitter", "paths", "hits", "adds"):
+            assert sa[k] == sb[k], k
