@@ -1270,6 +1270,8 @@ __global__ void __launch_bounds__(BLOCK) render_kernel(SceneView S, RenderParams
   }
 }
 
+#include "render_wf.inc"
+
 // -------------------------------------------------------------------------------------------------
 // batch closest-hit queries (rene_trace): one lane per ray
 // -------------------------------------------------------------------------------------------------
@@ -1347,6 +1349,16 @@ static hipError_t launch_feat(const LaunchConfig& cfg, const SceneView& S, const
   size_t lds = (FEAT & FEAT_SMALL) ? 0 : (size_t)cfg.stack_depth * BLOCK * sizeof(uint32_t);
   dim3 grid(cfg.grid), block(BLOCK);
   bool count = (P.flags & RENE_FLAG_COUNTERS) != 0, aov = !(P.flags & RENE_FLAG_NO_AOV);
+  if (!(FEAT & FEAT_SMALL) && !(P.flags & RENE_FLAG_NO_RESTART)) {  // BVH scenes: traversal-restart state machine
+    if (count) {
+      if (aov) hipLaunchKernelGGL((render_kernel_wf<FEAT, MAXL, true, true>), grid, block, lds, st, S, P);
+      else hipLaunchKernelGGL((render_kernel_wf<FEAT, MAXL, true, false>), grid, block, lds, st, S, P);
+    } else {
+      if (aov) hipLaunchKernelGGL((render_kernel_wf<FEAT, MAXL, false, true>), grid, block, lds, st, S, P);
+      else hipLaunchKernelGGL((render_kernel_wf<FEAT, MAXL, false, false>), grid, block, lds, st, S, P);
+    }
+    return hipGetLastError();
+  }
   if (count) {
     if (aov) hipLaunchKernelGGL((render_kernel<FEAT, MAXL, true, true>), grid, block, lds, st, S, P);
     else hipLaunchKernelGGL((render_kernel<FEAT, MAXL, true, false>), grid, block, lds, st, S, P);

@@ -1,0 +1,23 @@
+"""Developer script: throughput of every BASELINE config that fits one GPU (reduced spp)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rene_amd import scenes, api, abi
+
+def run(name, s, F, reps=3):
+    r = api.Renderer(s)
+    r.render(0, 4); r.sync(); r.reset()
+    for k in range(reps):
+        r.render(k * F, F)
+    r.sync()
+    st = r.stats()
+    with api.Renderer(s, flags=abi.FLAG_COUNTERS) as rc:
+        rc.render(0, 2); c = rc.stats()
+    print(f"{name}: {st.rays/st.kernel_ms/1e3:.0f} Mrays/s, {st.kernel_ms/st.frames:.3f} ms/frame, rays/path {st.rays/st.paths:.2f}, "
+          f"B_alg/ray {abi.algorithmic_bytes(c)/c.rays:.0f}, features {api.pack_info(s).features}", flush=True)
+    r.close()
+
+run("C2 cornell 1024x1024", scenes.cornell_box(1024, 1024), 64)
+run("C3 veach-mis 1024x1024", scenes.veach_mis(1024, 1024), 64)
+run("C3 veach-mis 1024x1024 (BVH)", scenes.veach_mis(1024, 1024), 64) if False else None
+run("C4 dragon-class 1920x1080", scenes.dragon_class(1920, 1080), 16)
+run("zoo 1024x768", scenes.material_zoo(1024, 768), 32)
