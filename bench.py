@@ -17,8 +17,8 @@ onto rank 0 -- is inside the timed region.  value = rays of all ranks / max-over
 
 The JSON line also carries
   roofline     -- dominant kernel (render_kernel): algorithmic bytes per launch (SURVEY.md 8d cache-less
-                  model, evaluated from the kernel's own node/primitive counters in an untimed
-                  counting pass) / average launch duration from HIP events recorded on the
+                  model, evaluated from the node/primitive counters of an untimed counting pass over
+                  this build's BVH2) / average launch duration from HIP events recorded on the
                   kernel's stream inside librene_hip.so, against the 8 TB/s HBM3E peak; `traffic` =
                   PMC-measured HBM bytes per launch when profiles/ holds them for this config;
   cpu_baseline -- the CPU oracle (a port of rene's integrator; the reference itself has no CPU
@@ -61,7 +61,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--cpu-spp", type=int, default=16, help="frames of the CPU-oracle baseline sample")
+    ap.add_argument("--cpu-spp", type=int, default=128, help="frames of the CPU-oracle baseline sample (~10 s on 16 threads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -94,8 +94,10 @@ def main():
                      framebuffer_ptr=fb.data_ptr())
 
     # ---- untimed: algorithmic bytes per ray from the kernel's own counters (same scene, seeds) ----
+    # (counted over this build's BVH2 -- RENE_FLAG_FORCE_BVH -- so that the figure does not depend on
+    # which intersection back end renders the scene: the small-scene item loop tests every item)
     cf = min(F, 8)
-    with api.Renderer(packed, device=local, flags=abi.FLAG_COUNTERS, shard_mode=abi.SHARD_TILES,
+    with api.Renderer(packed, device=local, flags=abi.FLAG_COUNTERS | abi.FLAG_FORCE_BVH, shard_mode=abi.SHARD_TILES,
                       shard_rank=rank, shard_count=world) as rc:
         rc.render(0, cf)
         cst = rc.stats()

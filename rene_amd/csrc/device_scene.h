@@ -182,6 +182,8 @@ struct RenderParams {
   uint32_t two_level;      // 1: every pixel is cut into a long and a short work item (ordered hand-off)
   uint32_t epoch;          // launch number (>= 1): value a long item publishes in item_done[]
   uint32_t* item_done;     // [n_work] per-pixel hand-off flags
+  uint32_t ready_min;      // traversal-restart kernel: lanes waiting before the logic step runs
+  uint32_t leaf_min;       // traversal-restart kernel: lanes at a leaf before the leaf step runs
 };
 
 }  // namespace rene

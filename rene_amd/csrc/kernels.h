@@ -14,6 +14,7 @@ struct LaunchConfig {
 };
 
 hipError_t launch_render(const LaunchConfig& cfg, const SceneView& S, const RenderParams& P, hipStream_t st);
+hipError_t launch_render_bvh(const LaunchConfig& cfg, const SceneView& S, const RenderParams& P, hipStream_t st);
 hipError_t launch_trace(const LaunchConfig& cfg, const SceneView& S, int which, uint32_t n, const float* o,
                         const float* d, float tmin, float tmax, rene_hit* out, hipStream_t st);
 hipError_t launch_bsdf_eval(const SceneView& S, uint32_t material, uint32_t n, const float* nrm3, const float* uv,

@@ -1,0 +1,33 @@
+// kernels_bvh.hip -- the BVH family of render kernels: the traversal-restart state machine
+// (render_kernel_wf, render_wf.inc) and, for A/B tests (RENE_FLAG_NO_RESTART), the plain while-while
+// kernel.  Separate translation unit so that it compiles in parallel with kernels.hip.
+#include "device_code.inc"  // opens namespace rene
+
+template <uint32_t FEAT, int MAXL>
+static hipError_t launch_bvh(const LaunchConfig& cfg, const SceneView& S, const RenderParams& P, hipStream_t st) {
+  static_assert(!(FEAT & FEAT_SMALL), "BVH family only");
+  size_t lds = (size_t)cfg.stack_depth * BLOCK * sizeof(uint32_t);
+  dim3 grid(cfg.grid), block(BLOCK);
+  bool count = (P.flags & RENE_FLAG_COUNTERS) != 0, aov = !(P.flags & RENE_FLAG_NO_AOV);
+  if (P.flags & RENE_FLAG_NO_RESTART) {
+    if (count || aov) hipLaunchKernelGGL((render_kernel<FEAT, MAXL, true, true>), grid, block, lds, st, S, P);
+    else hipLaunchKernelGGL((render_kernel<FEAT, MAXL, false, false>), grid, block, lds, st, S, P);
+    return hipGetLastError();
+  }
+  if (count) hipLaunchKernelGGL((render_kernel_wf<FEAT, MAXL, true, true>), grid, block, lds, st, S, P);
+  else if (aov) hipLaunchKernelGGL((render_kernel_wf<FEAT, MAXL, false, true>), grid, block, lds, st, S, P);
+  else hipLaunchKernelGGL((render_kernel_wf<FEAT, MAXL, false, false>), grid, block, lds, st, S, P);
+  return hipGetLastError();
+}
+
+hipError_t launch_render_bvh(const LaunchConfig& cfg, const SceneView& S, const RenderParams& P, hipStream_t st) {
+  constexpr uint32_t ALL = FEAT_SPHERES | FEAT_GENERAL_BSDF | FEAT_TEXTURES | FEAT_LIGHTS | FEAT_BACKGROUND | FEAT_MULTI_LOBE;
+  constexpr uint32_t GEN1 = ALL & ~FEAT_MULTI_LOBE;
+  const uint32_t f = cfg.features;
+  if (!(f & (FEAT_SPHERES | FEAT_GENERAL_BSDF | FEAT_TEXTURES | FEAT_BACKGROUND | FEAT_MULTI_LOBE)))
+    return launch_bvh<FEAT_LIGHTS, 1>(cfg, S, P, st);
+  if (!(f & FEAT_MULTI_LOBE)) return launch_bvh<GEN1, 1>(cfg, S, P, st);
+  return launch_bvh<ALL, 5>(cfg, S, P, st);
+}
+
+}  // namespace rene

@@ -359,6 +359,10 @@ int rene_render(rene_ctx* c, uint32_t first_frame, uint32_t n_frames) {
   }
   P.epoch = c->epoch;
   P.item_done = c->d_item_done;
+  P.ready_min = 20;  // tuned on the 870 k-triangle scene (tools/dev_sweep3.py): flat optimum 16-24 / 16
+  P.leaf_min = 16;
+  if (const char* e = std::getenv("RENE_READY_MIN")) P.ready_min = (uint32_t)std::max(1, std::atoi(e));  // tuning knobs
+  if (const char* e = std::getenv("RENE_LEAF_MIN")) P.leaf_min = (uint32_t)std::max(1, std::atoi(e));
   rene::LaunchConfig cfg = c->cfg;
   uint32_t blocks_needed = (c->n_work + rene::render_block_size() - 1) / rene::render_block_size();
   cfg.grid = std::max(1u, std::min(cfg.grid, blocks_needed));
