@@ -12,8 +12,8 @@ frames, so the K timed steps always render the full 1024 spp (a little more if K
 
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL).  The image is cut into 32x32
 tiles dealt round-robin to the ranks (strong scaling: total work is fixed); ranks never talk while
-rendering; the one exchange step -- an RCCL reduce(sum) of the [3][H][W][4] f32 accumulation image
-onto rank 0 -- is inside the timed region.  value = rays of all ranks / max-over-ranks time.
+rendering; the one exchange step -- an RCCL gather of each rank's own tiles (1/N of the [3][H][W][4]
+f32 accumulation image per rank) onto rank 0 -- is inside the timed region.  value = rays of all ranks / max-over-ranks time.
 
 The JSON line also carries
   roofline     -- dominant kernel (render_kernel): algorithmic bytes per launch (SURVEY.md 8d cache-less
@@ -108,7 +108,7 @@ def main():
         r.render(k * F, F)
     r.sync()
     if world > 1:
-        rdist.reduce_framebuffer(fb, dst=0)
+        rdist.gather_owned_tiles(fb, rank, world, dst=0)
         torch.cuda.synchronize()
     r.reset()
     fb.zero_()
@@ -125,7 +125,7 @@ def main():
         r.render(k * F, F)
     r.sync()
     if world > 1:
-        rdist.reduce_framebuffer(fb, dst=0)  # the one exchange step (RCCL over xGMI)
+        rdist.gather_owned_tiles(fb, rank, world, dst=0)  # the one exchange step (RCCL gather over xGMI)
     fence()
     elapsed = time.perf_counter() - t0
 
@@ -152,7 +152,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"cornell-box {WIDTH}x{HEIGHT} @ {spp} spp", "width": WIDTH, "height": HEIGHT,
                        "spp": spp, "frames_per_step": F, "triangles": scene.n_triangles,
-                       "sharding": f"32x32 tiles round-robin over {n_gpus} GPU(s) + RCCL reduce",
+                       "sharding": f"32x32 tiles round-robin over {n_gpus} GPU(s) + RCCL gather of owned tiles",
                        "seed": abi.DEFAULT_SEED},
             "rays": total_rays, "rays_per_path": total_rays / (WIDTH * HEIGHT * spp),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -42,6 +42,45 @@ def init_process_group(backend: str | None = None):
     dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
 
+def _tile_view(fb):
+    """[3][H][W][4] -> [tiles_y][tiles_x][3][32][32][4] view (H, W multiples of the tile size)."""
+    L, H, W, Cc = fb.shape
+    t = abi.TILE_SIZE
+    return fb.view(L, H // t, t, W // t, t, Cc).permute(1, 3, 0, 2, 4, 5)
+
+
+def gather_owned_tiles(fb, rank: int, world: int, dst: int = 0):
+    """The exchange step, tile-sharded form: every rank sends ONLY the 32x32 tiles it owns to `dst`
+    (1/world of the image per rank, all 7 xGMI links of `dst` in parallel) instead of summing whole
+    images -- each pixel has exactly one owner, so placing tiles equals the reduce bit for bit while
+    moving world x fewer bytes.  Falls back to `reduce_framebuffer` when the image is not a whole
+    number of tiles or the tile count does not divide evenly."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or world <= 1:
+        return fb
+    L, H, W, Cc = fb.shape
+    t = abi.TILE_SIZE
+    n_tiles = (H // t) * (W // t) if H % t == 0 and W % t == 0 else 0
+    if n_tiles == 0 or n_tiles % world != 0:
+        return reduce_framebuffer(fb, dst)
+    tv = _tile_view(fb).reshape(n_tiles, L, t, t, Cc)          # copy (permuted view -> contiguous)
+    idx = torch.arange(rank, n_tiles, world, device=fb.device)
+    mine = tv.index_select(0, idx).contiguous()                 # [n_tiles/world][3][32][32][4]
+    if mine.is_cuda and dist.get_backend() == "gloo":           # rehearsal backend: gloo gathers CPU tensors only
+        mine = mine.cpu()
+    if rank == dst:
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.gather(mine, gather_list=parts, dst=dst)
+        full = torch.empty_like(tv)
+        for r, part in enumerate(parts):
+            full.index_copy_(0, torch.arange(r, n_tiles, world, device=fb.device), part.to(fb.device))
+        fb.copy_(full.view(H // t, W // t, L, t, t, Cc).permute(2, 0, 3, 1, 4, 5).reshape(L, H, W, Cc))
+    else:
+        dist.gather(mine, gather_list=None, dst=dst)
+    return fb
+
+
 def reduce_framebuffer(fb, dst: int = 0):
     """Sum the per-rank accumulation images onto rank `dst` (ncclReduce over xGMI on GPUs)."""
     import torch.distributed as dist

@@ -20,6 +20,46 @@ def _free_port():
     return p
 
 
+def _gather_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    from rene_amd import abi, dist as rdist, scenes
+    from oracle import oracle
+    rdist.init_process_group("gloo")
+    o = oracle.Oracle(scenes.cornell_box(128, 96))  # 4 x 3 tiles, 12 % 2 == 0 and 12 % 3 == 0
+    o.render(0, 2, threads=1, shard_mode=abi.SHARD_TILES, shard_rank=rank, shard_count=world)
+    fb = torch.from_numpy(np.stack([o.download(l, 4) for l in range(3)]))
+    rdist.gather_owned_tiles(fb, rank, world, dst=0)
+    dist.barrier()
+    if rank == 0:
+        q.put(fb.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gather_owned_tiles_equals_single(world):
+    import torch.multiprocessing as mp
+    from rene_amd import scenes
+    from oracle import oracle
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    o = oracle.Oracle(scenes.cornell_box(128, 96))
+    o.render(0, 2, threads=1)
+    want = np.stack([o.download(l, 4) for l in range(3)])
+    assert np.array_equal(got, want)
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
