@@ -22,7 +22,12 @@ RENE_DEV f3 operator-(f3 a) { return {-a.x, -a.y, -a.z}; }
 RENE_DEV f3 operator*(f3 a, f3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
 RENE_DEV f3 operator*(f3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
 RENE_DEV f3 operator*(float s, f3 a) { return {a.x * s, a.y * s, a.z * s}; }
-RENE_DEV f3 operator/(f3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+RENE_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }   // v_rcp_f32, 1 ulp
+RENE_DEV float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }   // v_rsq_f32, 1 ulp
+RENE_DEV f3 operator/(f3 a, float s) {
+  float r = fast_rcp(s);
+  return {a.x * r, a.y * r, a.z * r};
+}
 RENE_DEV f3 operator/(f3 a, f3 b) { return {a.x / b.x, a.y / b.y, a.z / b.z}; }
 RENE_DEV float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 RENE_DEV f3 cross(f3 a, f3 b) {
@@ -30,7 +35,10 @@ RENE_DEV f3 cross(f3 a, f3 b) {
 }
 RENE_DEV float length_squared(f3 a) { return dot(a, a); }
 RENE_DEV float length(f3 a) { return sqrtf(dot(a, a)); }
-RENE_DEV f3 normalize(f3 a) { return a / length(a); }
+RENE_DEV f3 normalize(f3 a) {
+  float r = fast_rsq(dot(a, a));
+  return {a.x * r, a.y * r, a.z * r};
+}
 RENE_DEV float max_element(f3 a) { return fmaxf(a.x, fmaxf(a.y, a.z)); }
 RENE_DEV bool is_zero(f3 a) { return a.x == 0.0f && a.y == 0.0f && a.z == 0.0f; }
 RENE_DEV f3 sqrt3(f3 a) { return {sqrtf(a.x), sqrtf(a.y), sqrtf(a.z)}; }
@@ -44,6 +52,11 @@ RENE_DEV f3 m4_point(const float* m, f3 p) {
 RENE_DEV f3 m4_vector(const float* m, f3 p) {
   return {m[0] * p.x + m[4] * p.y + m[8] * p.z, m[1] * p.x + m[5] * p.y + m[9] * p.z,
           m[2] * p.x + m[6] * p.y + m[10] * p.z};
+}
+typedef const __attribute__((address_space(4))) float* cfloat_ptr;  // constant address space -> scalar loads
+RENE_DEV f3 m4_point(cfloat_ptr m, f3 p) {
+  return {m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12], m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
+          m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14]};
 }
 // 3x4 affine stored as x,y,z,w column vectors
 RENE_DEV f3 aff_point(const float* m, f3 p) {
@@ -77,6 +90,10 @@ RENE_DEV float pcg_f32(Pcg& r) {  // rand.rs:38-47
   return (1.0f / 16777216.0f) * (float)(pcg_u32(r) >> 8);
 }
 RENE_DEV float pcg_range(Pcg& r, float lo, float hi) { return lo + (hi - lo) * pcg_f32(r); }
+
+// x % n: a 32-bit remainder is ~20 VALU instructions on CDNA; n is 1 or a small power of two in
+// most scenes (lobe count, emitter count, triangles of a quad emitter), which is a single AND
+RENE_DEV uint32_t umod(uint32_t x, uint32_t n) { return (n & (n - 1u)) == 0u ? (x & (n - 1u)) : (x % n); }
 
 // sin/cos of 2*pi*x for x in [0,1): v_sin_f32 / v_cos_f32 take their argument in revolutions
 RENE_DEV float sin_2pi(float x) { return __builtin_amdgcn_sinf(x); }

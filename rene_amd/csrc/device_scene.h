@@ -133,6 +133,16 @@ struct Accel {
   uint32_t pad;
 };
 
+// Uniform, rene-shader/src/lib.rs:90-102: kept in memory rather than in the kernel arguments -- 52
+// floats pinned in SGPRs for the whole persistent loop made the compiler spill SGPRs into VGPR lanes
+// (v_writelane / v_readlane in the hot loop); they are needed once per path only
+struct Uniforms {
+  float c2w[16];
+  float proj_inv[16];
+  float bg_matrix[16];
+  float bg_color[4];
+};
+
 // everything a kernel needs, passed by value (lives in SGPRs / kernarg)
 struct SceneView {
   Accel main;
@@ -148,10 +158,7 @@ struct SceneView {
   const Light* lights;
   const ImageRef* images;
   const float* image_pool;
-  float c2w[16];
-  float proj_inv[16];
-  float bg_matrix[16];
-  float bg_color[4];
+  const struct Uniforms* uni;  // camera / background block (read on demand through the scalar cache)
   uint32_t bg_texture;
   uint32_t lights_len;
   uint32_t emit_object_len;

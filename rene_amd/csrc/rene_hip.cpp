@@ -235,10 +235,15 @@ int rene_create(const rene_scene_desc* scene, const rene_opts* opts, rene_ctx** 
   UP(ps.images, v.images);
   UP(ps.image_pool, v.image_pool);
 #undef UP
-  std::memcpy(v.c2w, ps.uniform.camera_to_world, 64);
-  std::memcpy(v.proj_inv, ps.uniform.projection_inv, 64);
-  std::memcpy(v.bg_matrix, ps.uniform.background_matrix, 64);
-  std::memcpy(v.bg_color, ps.uniform.background_color, 16);
+  {
+    std::vector<rene::Uniforms> u(1);
+    std::memcpy(u[0].c2w, ps.uniform.camera_to_world, 64);
+    std::memcpy(u[0].proj_inv, ps.uniform.projection_inv, 64);
+    std::memcpy(u[0].bg_matrix, ps.uniform.background_matrix, 64);
+    std::memcpy(u[0].bg_color, ps.uniform.background_color, 16);
+    int rc_ = c->upload(u, &v.uni);
+    if (rc_ != RENE_OK) return rc_;
+  }
   v.bg_texture = ps.uniform.background_texture;
   v.lights_len = (uint32_t)ps.lights.size();                // rene/src/scene.rs:166
   v.emit_object_len = (uint32_t)ps.emit_objects.size();     // rene/src/main.rs:3279
