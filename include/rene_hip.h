@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RENE_ABI_VERSION 1u
+#define RENE_ABI_VERSION 2u
 
 typedef enum rene_status {
   RENE_OK = 0,
@@ -126,6 +126,15 @@ typedef struct rene_light {
   float v1[4];
 } rene_light;
 
+/* EnumMedium, rene-shader/src/medium.rs:47-72.  Homogeneous: v0 = sigma_a.rgb, g; v1 = sigma_s.rgb, 0
+ * (medium.rs:78-84).  Only the volumetric integrator reads media. */
+enum { RENE_MEDIUM_VACUUM = 0, RENE_MEDIUM_HOMOGENEOUS = 1 };
+typedef struct rene_medium {
+  uint32_t type;
+  float v0[4];
+  float v1[4];
+} rene_medium;
+
 /* Image, rene/src/scene/image.rs:1-19: linear RGBA32F, row 0 first. */
 typedef struct rene_image {
   const float* rgba;
@@ -167,6 +176,9 @@ typedef struct rene_scene_desc {
   const rene_area_light* area_lights; /* [0] is the Null sentinel, rene/src/scene.rs:110 */
   const rene_light* lights;
   const rene_image* images;
+  const rene_medium* mediums;       /* [0] is the Vacuum sentinel, rene/src/scene.rs:111; may be NULL when n_mediums == 0 */
+  uint32_t n_mediums;
+  uint32_t reserved;
 } rene_scene_desc;
 
 /* ---- render options (additive; the reference hard-codes these, rene/src/main.rs:77-81, 1301) - */
@@ -277,6 +289,15 @@ int rene_trace(rene_ctx* ctx, int which, size_t n, const float* origins, const f
 int rene_bsdf_eval(rene_ctx* ctx, uint32_t material_index, size_t n, const float* normals3,
                    const float* uvs2, const float* wo3, const float* wi3, const uint32_t* seeds,
                    float* out12);
+
+/* Per-function probe of the device medium code (EnumMedium::{tr, phase, sample, sample_p},
+ * rene-shader/src/medium.rs:104-158) for n items with ray origin 0.  Writes 16 floats per item:
+ * tr(rd, t_max).rgb, phase(wo, wi), sample.sampled (0/1), sample.position.xyz, sample.tr.rgb,
+ * sample_p(wo).xyz (drawn after `sample` from the same PCG32si::new(seed)), the bits of the stream's
+ * next u32, 0.  Host pointers.  RENE_ERR_INVALID_ARGUMENT unless the scene's integrator is volpath. */
+int rene_medium_eval(rene_ctx* ctx, uint32_t medium_index, size_t n, const float* rd3,
+                     const float* t_max, const float* wo3, const float* wi3, const uint32_t* seeds,
+                     float* out16);
 
 void rene_destroy(rene_ctx* ctx);
 

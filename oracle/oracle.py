@@ -49,6 +49,7 @@ def lib():
         L.oracle_camera_ray.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
         L.oracle_bsdf_eval.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_uint32, C.c_void_p]
+        L.oracle_medium_eval.argtypes = [C.c_void_p, C.c_uint32, C.c_size_t] + [C.c_void_p] * 6
         L.oracle_fr_dielectric.argtypes = [C.c_float, C.c_float, C.c_float, C.c_void_p]
         L.oracle_fr_conductor.argtypes = [C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_tr_d_lambda.argtypes = [C.c_float, C.c_float, C.c_void_p, C.c_void_p]
@@ -120,6 +121,14 @@ class Oracle:
         lib().oracle_bsdf_eval(self._h, material_index, _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), seed, _p(out))
         return {"f": out[0:3].copy(), "pdf": float(out[3]), "s_wi": out[4:7].copy(),
                 "s_f": out[7:10].copy(), "s_pdf": float(out[10]), "len": int(out[11])}
+
+    def medium_eval(self, medium_index, rd, t_max, wo, wi, seeds) -> np.ndarray:
+        """(n, 16) float32, layout of rene_medium_eval (include/rene_hip.h)."""
+        a = [np.ascontiguousarray(v, dtype=np.float32) for v in (rd, t_max, wo, wi)]
+        sd = np.ascontiguousarray(seeds, dtype=np.uint32)
+        out = np.zeros((sd.size, 16), np.float32)
+        lib().oracle_medium_eval(self._h, medium_index, sd.size, _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(sd), _p(out))
+        return out
 
     def tex_color(self, tex: int, u: float, v: float) -> np.ndarray:
         out = np.zeros(3, np.float32)

@@ -722,6 +722,7 @@ struct Vertex {  // lib.rs:883-890
 };
 struct IndexData {  // lib.rs:108-118
   uint32_t material_index, area_light_index, index_offset, primitive_count;
+  uint32_t interior_medium_index, exterior_medium_index;
 };
 struct EmitObject {  // surface_sample.rs:20-33
   int type;          // 0 triangle, 1 sphere
@@ -774,6 +775,8 @@ struct Scene {
   struct Img { uint32_t w, h; std::vector<float> rgba; };
   std::vector<Img> images;
   std::vector<EmitObject> emit_objects;  // main.rs:3143-3158
+  std::vector<rene_medium> mediums;      // [0] = vacuum, scene.rs:111
+  uint32_t integrator = RENE_INTEGRATOR_PATH;
   uint32_t emit_object_len = 0, lights_len = 0;
   Bvh tlas_main, tlas_emit;
   std::vector<uint32_t> tlas_main_inst, tlas_emit_inst;  // instance ids per TLAS leaf slot
@@ -1150,6 +1153,204 @@ struct Scene {
            tex_color(uni.background_texture, uv);
   }
 
+  // ---- medium.rs:103-158 Homogeneous; 190-218 EnumMedium dispatch ----
+  static V3 exp3(V3 a) { return v3(std::exp(a.x), std::exp(a.y), std::exp(a.z)); }
+  V3 medium_tr(const rene_medium& m, V3 dir, float t_max) const {  // medium.rs:104-106
+    if (m.type == RENE_MEDIUM_VACUUM) return ONE3;
+    V3 sigma_t = v3(m.v0[0], m.v0[1], m.v0[2]) + v3(m.v1[0], m.v1[1], m.v1[2]);
+    return exp3(-sigma_t * length(dir) * t_max);
+  }
+  struct SampledMedium {
+    bool sampled = false;
+    V3 position = ZERO3, tr = ONE3;
+  };
+  SampledMedium medium_sample(const rene_medium& m, V3 ro, V3 rd, float t_max, PCG32si& rng) const {  // medium.rs:108-132
+    SampledMedium s;
+    if (m.type == RENE_MEDIUM_VACUUM) return s;
+    uint32_t channel = rng.next_u32() % 3;
+    V3 sigma_s = v3(m.v1[0], m.v1[1], m.v1[2]);
+    V3 sigma_t = v3(m.v0[0], m.v0[1], m.v0[2]) + sigma_s;
+    float st[3] = {sigma_t.x, sigma_t.y, sigma_t.z};
+    float dist = -std::log(1.0f - rng.next_f32()) / st[channel];
+    float t = dist / length(rd);
+    bool sampled = t < t_max;
+    t = std::min(t, t_max);
+    V3 tr = exp3(-sigma_t * t * length(rd));
+    V3 density = sampled ? sigma_t * tr : tr;
+    float pdf = (density.x + density.y + density.z) / 3.0f;
+    if (pdf == 0.0f) pdf = 1.0f;
+    s.sampled = sampled;
+    s.position = ro + t * rd;
+    s.tr = sampled ? tr * sigma_s / pdf : tr / pdf;
+    return s;
+  }
+  float medium_phase(const rene_medium& m, V3 wo, V3 wi) const {  // medium.rs:134-139 (Henyey-Greenstein)
+    if (m.type == RENE_MEDIUM_VACUUM) return 0.0f;
+    float cos_theta = dot(wo, wi);
+    float g = m.v0[3];
+    float denom = 1.0f + g * g + 2.0f * g * cos_theta;
+    return 1.0f / (4.0f * PI) * (1.0f - g * g) / (denom * std::sqrt(denom));
+  }
+  V3 medium_sample_p(const rene_medium& m, V3 wo, PCG32si& rng) const {  // medium.rs:141-157
+    if (m.type == RENE_MEDIUM_VACUUM) return ZERO3;
+    float u0 = rng.next_f32();
+    float u1 = rng.next_f32();
+    float g = m.v0[3];
+    float cos_theta;
+    if (std::fabs(g) < 1e-3f) {
+      cos_theta = 1.0f - 2.0f * u0;
+    } else {
+      float sqr_term = (1.0f - g * g) / (1.0f + g - 2.0f * g * u0);
+      cos_theta = -(1.0f + g * g - sqr_term * sqr_term) / (2.0f * g);
+    }
+    float sin_theta = std::sqrt(std::max(1.0f - cos_theta * cos_theta, 0.0f));
+    float phi = 2.0f * PI * u1;
+    V3 v1, v2;
+    coordinate_system(wo, v1, v2);
+    return sin_theta * std::cos(phi) * v1 + sin_theta * std::sin(phi) * v2 + cos_theta * wo;  // medium.rs:12-21
+  }
+
+  // ---- lib.rs:359-409 tr / 411-468 tr_emit: transmittance along a ray through None-material surfaces ----
+  V3 tr_through(V3 ro, V3 rd, uint32_t medium_index, bool emit, Counters& c) const {
+    V3 tr = ONE3;
+    for (int guard = 0; guard < 4096; ++guard) {
+      c.rays_shadow++;
+      Hit h = trace(tlas_main, tlas_main_inst, ro, rd, 0.001f, 1e5f, false, c);
+      if (h.miss) return emit ? ZERO3 : tr;
+      Payload p = closest_hit(h, ro, rd);
+      const IndexData& index = index_data[p.index];
+      if (emit && area_lights[index.area_light_index].type != RENE_AREA_LIGHT_NULL) {  // lib.rs:447-451
+        V3 wo = -normalize(rd);
+        const rene_area_light& al = area_lights[index.area_light_index];
+        V3 e = dot(wo, p.normal) > 0.0f ? v3(al.v0[0], al.v0[1], al.v0[2]) : ZERO3;  // NB: payload.normal, not re-normalised
+        return tr * e;
+      }
+      if (materials[index.material_index].type != RENE_MATERIAL_NONE) return ZERO3;
+      const rene_medium& medium = mediums[medium_index];
+      if (medium.type != RENE_MEDIUM_VACUUM) tr *= medium_tr(medium, rd, p.t);
+      medium_index = dot(rd, p.normal) > 0.0f ? index.exterior_medium_index : index.interior_medium_index;
+      ro = p.position;
+    }
+    return tr;
+  }
+
+  // ---- lib.rs:477-803 main_ray_generation_volpath; one (pixel, frame) ----
+  void raygen_volpath(uint32_t x, uint32_t y, uint32_t seed, Counters& c) {
+    auto add_image = [&](uint32_t layer, V3 v) {
+      float* p = &image[(((size_t)layer * H + (H - 1 - y)) * W + x) * 4];
+      p[0] = p[0] + v.x; p[1] = p[1] + v.y; p[2] = p[2] + v.z; p[3] = p[3] + 0.0f;
+      c.adds++;
+    };
+    c.paths++;
+    PCG32si rng((y * W + x) ^ seed);
+    PCG32si frame_wide_rng(seed);
+    float u = ((float)x + rng.next_f32()) / (float)(W - 1);
+    float v = ((float)y + rng.next_f32()) / (float)(H - 1);
+    const float tmin = 0.001f, tmax = 100000.0f;
+    Bsdf bsdf;
+    bsdf.onb = Onb::from_w(v3(0.f, 0.f, 1.f));
+    V3 color = ONE3;
+    V3 ro, rd;
+    camera_ray(u, v, ro, rd);
+    uint32_t medium_index = 0;
+    uint32_t i = 0;
+    while (i < 80) {  // MAX_DEPTH, lib.rs:499
+      c.rays_closest++;
+      Hit h = trace(tlas_main, tlas_main_inst, ro, rd, tmin, tmax, false, c);
+      if (h.miss) {
+        add_image(0, color * miss_color(rd));
+        break;
+      } else {
+        Payload payload = closest_hit(h, ro, rd);
+        c.hits++;
+        c.bounces++;
+        V3 wo = -normalize(rd);
+        V3 normal = normalize(payload.normal);
+        V3 position = payload.position;
+        V2 uv = payload.uv;
+        const IndexData& index = index_data[payload.index];
+        const rene_material& material = materials[index.material_index];
+        const rene_area_light& area_light = area_lights[index.area_light_index];
+        const rene_medium& medium = mediums[medium_index];
+        SampledMedium sm = medium_sample(medium, ro, rd, payload.t, rng);  // lib.rs:563
+        color *= sm.tr;
+        if (sm.sampled) {  // scattering inside the medium, lib.rs:567-656
+          ro = sm.position;
+          for (uint32_t l = 0; l < lights_len; ++l) {
+            const rene_light& lt = lights[l];
+            V3 wi = normalize((ro + v3(lt.v0[0], lt.v0[1], lt.v0[2])) - ro);
+            V3 tr = tr_through(ro, wi, medium_index, false, c);
+            add_image(0, color * tr * medium_phase(medium, wo, wi) * v3(lt.v1[0], lt.v1[1], lt.v1[2]));
+          }
+          if (emit_object_len > 0) {  // lib.rs:599-654: uses the PIXEL rng here, not the frame-wide one
+            const EmitObject& eo = emit_objects[rng.next_u32() % emit_object_len];
+            V3 wi = normalize(emit_sample(eo, rng) - ro);
+            c.rays_emitter++;
+            Hit eh = trace(tlas_emit, tlas_emit_inst, ro, wi, tmin, tmax, false, c);
+            float pdf_l = closest_hit_pdf(eh, ro, wi);
+            V3 tr = tr_through(ro, wi, medium_index, true, c);
+            float pdf = pdf_l / (float)emit_object_len;
+            if (pdf > 1e-5f) add_image(0, color * tr * medium_phase(medium, wo, wi) / pdf);
+          }
+          rd = medium_sample_p(medium, wo, rng);  // lib.rs:656
+        } else {  // surface interaction, lib.rs:657-780
+          bsdf.clear(normal, Onb::from_w(normal));
+          compute_bsdf(material, bsdf, uv);
+          if (area_light.type != RENE_AREA_LIGHT_NULL) {
+            V3 e = dot(wo, normal) > 0.0f ? v3(area_light.v0[0], area_light.v0[1], area_light.v0[2]) : ZERO3;
+            add_image(0, color * e);
+          }
+          if (i == 0) {
+            add_image(1, normal);
+            add_image(2, albedo(material, uv));
+          }
+          if (material.type != RENE_MATERIAL_NONE) {
+            for (uint32_t l = 0; l < lights_len; ++l) {  // lib.rs:671-701
+              const rene_light& lt = lights[l];
+              V3 wi = normalize((position + v3(lt.v0[0], lt.v0[1], lt.v0[2])) - position);
+              V3 f = bsdf.f(wo, wi);
+              V3 tr = tr_through(position, wi, medium_index, false, c);
+              add_image(0, color * tr * f * std::fabs(dot(wi, normal)) * v3(lt.v1[0], lt.v1[1], lt.v1[2]));
+            }
+            if (emit_object_len > 0 && bsdf.contains(K_DIFFUSE)) {  // lib.rs:703-754
+              V3 wi, f;
+              float pdf;
+              if (frame_wide_rng.next_f32() > 0.5f) {
+                const EmitObject& eo = emit_objects[frame_wide_rng.next_u32() % emit_object_len];
+                wi = normalize(emit_sample(eo, frame_wide_rng) - position);
+                pdf = bsdf.pdf(wi, normal);
+                f = bsdf.f(wo, wi);
+              } else {
+                SampledF s = bsdf.sample_f(wo, rng);
+                wi = s.wi; pdf = s.pdf; f = s.f;
+              }
+              ro = position;
+              rd = wi;
+              c.rays_emitter++;
+              Hit eh = trace(tlas_emit, tlas_emit_inst, ro, rd, tmin, tmax, false, c);
+              float pdf_l = closest_hit_pdf(eh, ro, rd);
+              color *= f * std::fabs(dot(normal, wi));
+              pdf = 0.5f * pdf + 0.5f * pdf_l / (float)emit_object_len;
+              if (pdf < 1e-5f) break;
+              color /= pdf;
+            } else {  // lib.rs:755-767
+              SampledF s = bsdf.sample_f(wo, rng);
+              if (s.pdf < 1e-5f) break;
+              color *= s.f * std::fabs(dot(normal, s.wi)) / s.pdf;
+              ro = position;
+              rd = s.wi;
+            }
+          } else {  // None material: the boundary of a medium, pass straight through (lib.rs:768-773)
+            ro = payload.position;
+          }
+          medium_index = dot(wo, normal) < 0.0f ? index.exterior_medium_index : index.interior_medium_index;  // lib.rs:775-779
+        }
+      }
+      if (color == ZERO3) break;  // lib.rs:783-785 (Russian roulette is commented out, 787-799)
+      i += 1;
+    }
+  }
+
   // ---- lib.rs:141-357 main_ray_generation_path; one (pixel, frame) ----
   void raygen(uint32_t x, uint32_t y, uint32_t seed, Counters& c) {
     auto add_image = [&](uint32_t layer, V3 v) {  // lib.rs:165-172
@@ -1274,7 +1475,7 @@ const char* oracle_last_error() { return g_err.c_str(); }
 
 int oracle_create(const rene_scene_desc* d, oracle_ctx** out) {
   if (!d || !out || d->struct_size != sizeof(rene_scene_desc)) { g_err = "bad scene desc"; return -1; }
-  if (d->integrator != RENE_INTEGRATOR_PATH) { g_err = "volpath not restated"; return -4; }
+  if (d->integrator != RENE_INTEGRATOR_PATH && d->integrator != RENE_INTEGRATOR_VOLPATH) { g_err = "unknown integrator"; return -4; }
   auto ctx = std::make_unique<oracle_ctx>();
   Scene& s = ctx->s;
   s.W = d->xresolution; s.H = d->yresolution;
@@ -1303,6 +1504,9 @@ int oracle_create(const rene_scene_desc* d, oracle_ctx** out) {
   s.area_lights.assign(d->area_lights, d->area_lights + d->n_area_lights);
   s.lights.assign(d->lights, d->lights + d->n_lights);
   s.lights_len = d->n_lights;  // scene.rs:166
+  s.integrator = d->integrator;
+  if (d->n_mediums) s.mediums.assign(d->mediums, d->mediums + d->n_mediums);
+  else { rene_medium vac{}; vac.type = RENE_MEDIUM_VACUUM; s.mediums.push_back(vac); }  // scene.rs:111
   for (uint32_t i = 0; i < d->n_images; ++i) {
     Scene::Img im{d->images[i].width, d->images[i].height, {}};
     im.rgba.assign(d->images[i].rgba, d->images[i].rgba + (size_t)4 * im.w * im.h);
@@ -1349,8 +1553,11 @@ int oracle_create(const rene_scene_desc* d, oracle_ctx** out) {
     id.area_light_index = ri.area_light_index;
     id.index_offset = ri.shape == RENE_SHAPE_TRIANGLE ? s.mesh_index_offset[ri.mesh_index] : 0;
     id.primitive_count = ri.shape == RENE_SHAPE_TRIANGLE ? s.mesh_prim_count[ri.mesh_index] : 1;
+    id.interior_medium_index = ri.interior_medium_index;
+    id.exterior_medium_index = ri.exterior_medium_index;
     s.index_data.push_back(id);
     if (ri.material_index >= d->n_materials || ri.area_light_index >= d->n_area_lights) { g_err = "bad table index"; return -2; }
+    if (ri.interior_medium_index >= s.mediums.size() || ri.exterior_medium_index >= s.mediums.size()) { g_err = "bad medium index"; return -2; }
     main_boxes.push_back(in.world_box);
     s.tlas_main_inst.push_back(i);
     if (s.area_lights[ri.area_light_index].type != RENE_AREA_LIGHT_NULL) {  // main.rs:3109-3116, 3143-3158
@@ -1411,7 +1618,8 @@ int oracle_render(oracle_ctx* c, uint32_t master_seed, uint32_t first_frame, uin
           if (shard_mode == RENE_SHARD_FRAMES && shard_count > 1 &&
               (first_frame + k) % shard_count != shard_rank)
             continue;
-          s.raygen(x, y, seeds[k], cc);
+          if (s.integrator == RENE_INTEGRATOR_VOLPATH) s.raygen_volpath(x, y, seeds[k], cc);
+          else s.raygen(x, y, seeds[k], cc);
         }
       }
     }
@@ -1535,6 +1743,28 @@ void oracle_bsdf_eval(oracle_ctx* c, uint32_t material_index, const float* n3, c
   out12[0] = f.x; out12[1] = f.y; out12[2] = f.z; out12[3] = p;
   out12[4] = sf.wi.x; out12[5] = sf.wi.y; out12[6] = sf.wi.z;
   out12[7] = sf.f.x; out12[8] = sf.f.y; out12[9] = sf.f.z; out12[10] = sf.pdf; out12[11] = (float)b.len;
+}
+// per-function probe of the medium code (medium.rs:104-158) for n items, ray origin 0:
+// out16 = tr(rd,t_max).rgb, phase(wo,wi), sample.sampled, sample.position.xyz, sample.tr.rgb,
+//         sample_p(wo).xyz (drawn after `sample` from the same PCG32si::new(seed)), bits(rng.next_u32()), 0
+void oracle_medium_eval(oracle_ctx* c, uint32_t medium_index, size_t n, const float* rd3, const float* t_max,
+                        const float* wo3, const float* wi3, const uint32_t* seeds, float* out16) {
+  Scene& s = c->s;
+  const rene_medium& m = s.mediums[medium_index];
+  for (size_t i = 0; i < n; ++i) {
+    V3 rd = v3(rd3[3 * i], rd3[3 * i + 1], rd3[3 * i + 2]);
+    V3 wo = v3(wo3[3 * i], wo3[3 * i + 1], wo3[3 * i + 2]), wi = v3(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]);
+    float* o = out16 + 16 * i;
+    V3 tr = s.medium_tr(m, rd, t_max[i]);
+    PCG32si rng(seeds[i]);
+    Scene::SampledMedium sm = s.medium_sample(m, ZERO3, rd, t_max[i], rng);
+    V3 p = s.medium_sample_p(m, wo, rng);
+    uint32_t next = rng.next_u32();
+    o[0] = tr.x; o[1] = tr.y; o[2] = tr.z; o[3] = s.medium_phase(m, wo, wi);
+    o[4] = sm.sampled ? 1.0f : 0.0f; o[5] = sm.position.x; o[6] = sm.position.y; o[7] = sm.position.z;
+    o[8] = sm.tr.x; o[9] = sm.tr.y; o[10] = sm.tr.z; o[11] = p.x; o[12] = p.y; o[13] = p.z;
+    std::memcpy(&o[14], &next, 4); o[15] = 0.0f;
+  }
 }
 void oracle_fr_dielectric(float c, float ei, float et, float* out) { *out = fr_dielectric(c, ei, et); }
 void oracle_fr_conductor(float c, const float* ei, const float* et, const float* k, float* out3) {

@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 DEFAULT_SEED = 0x52454E45
 TILE_SIZE = 32
 
@@ -63,6 +63,13 @@ class Light(C.Structure):
     _fields_ = [("type", u32), ("v0", f32 * 4), ("v1", f32 * 4)]
 
 
+MEDIUM_VACUUM, MEDIUM_HOMOGENEOUS = 0, 1
+
+
+class Medium(C.Structure):
+    _fields_ = [("type", u32), ("v0", f32 * 4), ("v1", f32 * 4)]
+
+
 class Image(C.Structure):
     _fields_ = [("rgba", C.POINTER(f32)), ("width", u32), ("height", u32)]
 
@@ -82,7 +89,8 @@ class SceneDesc(C.Structure):
                 ("instances", C.POINTER(Instance)), ("meshes", C.POINTER(Mesh)),
                 ("materials", C.POINTER(Material)), ("textures", C.POINTER(Texture)),
                 ("area_lights", C.POINTER(AreaLight)), ("lights", C.POINTER(Light)),
-                ("images", C.POINTER(Image))]
+                ("images", C.POINTER(Image)), ("mediums", C.POINTER(Medium)), ("n_mediums", u32),
+                ("reserved", u32)]
 
 
 class Opts(C.Structure):
@@ -134,7 +142,7 @@ def algorithmic_bytes(stats) -> int:
 # every symbol include/rene_hip.h declares (tests check that the shared library exports them all)
 EXPORTED_SYMBOLS = [
     "rene_create", "rene_render", "rene_sync", "rene_download", "rene_reset", "rene_framebuffer",
-    "rene_get_stats", "rene_trace", "rene_bsdf_eval", "rene_destroy", "rene_scene_pack_info", "rene_last_error", "rene_abi_version",
+    "rene_get_stats", "rene_trace", "rene_bsdf_eval", "rene_medium_eval", "rene_destroy", "rene_scene_pack_info", "rene_last_error", "rene_abi_version",
     "rene_to_rgb8", "rene_to_aov8", "rene_frame_seeds",
     "rene_scene_load_pbrt", "rene_scene_parse_pbrt", "rene_scene_get_desc",
     "rene_scene_film_filename", "rene_scene_free",

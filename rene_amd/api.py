@@ -59,6 +59,7 @@ def lib():
     L.rene_get_stats.argtypes = [vp, C.POINTER(abi.Stats)]
     L.rene_trace.argtypes = [vp, i32, C.c_size_t, vp, vp, C.c_float, C.c_float, vp]
     L.rene_bsdf_eval.argtypes = [vp, u32, C.c_size_t, vp, vp, vp, vp, vp, vp]
+    L.rene_medium_eval.argtypes = [vp, u32, C.c_size_t, vp, vp, vp, vp, vp, vp]
     L.rene_destroy.argtypes = [vp]
     L.rene_scene_pack_info.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(abi.PackInfo)]
     L.rene_destroy.restype = None
@@ -176,6 +177,19 @@ def _bsdf_eval(self, material_index: int, normals, uvs, wo, wi, seeds) -> np.nda
 
 
 Renderer.bsdf_eval = _bsdf_eval
+
+
+def _medium_eval(self, medium_index: int, rd, t_max, wo, wi, seeds) -> np.ndarray:
+    """Device medium probe (volpath scenes): (n, 16), layout of rene_medium_eval in include/rene_hip.h."""
+    a = [np.ascontiguousarray(v, dtype=np.float32) for v in (rd, t_max, wo, wi)]
+    sd = np.ascontiguousarray(seeds, dtype=np.uint32)
+    out = np.zeros((sd.size, 16), np.float32)
+    p = lambda x: x.ctypes.data_as(C.c_void_p)
+    _check(lib().rene_medium_eval(self._h, medium_index, sd.size, p(a[0]), p(a[1]), p(a[2]), p(a[3]), p(sd), p(out)))
+    return out
+
+
+Renderer.medium_eval = _medium_eval
 
 
 def pack_info(scene) -> abi.PackInfo:

@@ -103,6 +103,15 @@ struct ImageRef {
   uint64_t offset;  // float offset into the image pool
   uint32_t width, height;
 };
+// ---- participating media (volpath integrator only) ---------------------------------------------------
+struct Medium {  // EnumMedium, medium.rs:60-74: sigma_a.rgb g | sigma_s.rgb bits(type)
+  float sa_g[4];
+  float ss_t[4];
+};
+struct InstMedium {  // IndexData::{interior,exterior}_medium_index, lib.rs:108-118; kept out of Inst so
+  uint32_t interior; // that the path integrator's per-hit record stays 48 bytes
+  uint32_t exterior;
+};
 
 // ---- small-scene item list (<= SMALL_MAX_ITEMS primitives per structure) ----------------------------
 // Scenes this small are intersected by a wave-coherent loop over every item instead of a BVH: all 64
@@ -159,6 +168,8 @@ struct SceneView {
   const ImageRef* images;
   const float* image_pool;
   const struct Uniforms* uni;  // camera / background block (read on demand through the scalar cache)
+  const Medium* mediums;          // volpath only; [0] is the vacuum
+  const InstMedium* inst_medium;  // volpath only; per instance
   uint32_t bg_texture;
   uint32_t lights_len;
   uint32_t emit_object_len;
@@ -174,6 +185,7 @@ enum : uint32_t {
   FEAT_BACKGROUND = 1u << 4,   // non-black background
   FEAT_MULTI_LOBE = 1u << 5,   // Plastic / Uber (more than one lobe)
   FEAT_SMALL = 1u << 6,        // both structures fit the wave-coherent item loop (no BVH traversal)
+  FEAT_VOLPATH = 1u << 7,      // Integrator "volpath": media, None-material boundaries, depth 80, no roulette
 };
 
 struct RenderParams {

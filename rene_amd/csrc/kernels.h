@@ -15,10 +15,13 @@ struct LaunchConfig {
 
 hipError_t launch_render(const LaunchConfig& cfg, const SceneView& S, const RenderParams& P, hipStream_t st);
 hipError_t launch_render_bvh(const LaunchConfig& cfg, const SceneView& S, const RenderParams& P, hipStream_t st);
+hipError_t launch_render_vol(const LaunchConfig& cfg, const SceneView& S, const RenderParams& P, hipStream_t st);
 hipError_t launch_trace(const LaunchConfig& cfg, const SceneView& S, int which, uint32_t n, const float* o,
                         const float* d, float tmin, float tmax, rene_hit* out, hipStream_t st);
 hipError_t launch_bsdf_eval(const SceneView& S, uint32_t material, uint32_t n, const float* nrm3, const float* uv,
                             const float* wo3, const float* wi3, const uint32_t* seeds, float* out, hipStream_t st);
+hipError_t launch_medium_eval(const SceneView& S, uint32_t medium, uint32_t n, const float* rd3, const float* t_max,
+                              const float* wo3, const float* wi3, const uint32_t* seeds, float* out, hipStream_t st);
 int render_block_size();
 
 }  // namespace rene

@@ -73,6 +73,34 @@ hipError_t launch_bsdf_eval(const SceneView& S, uint32_t material, uint32_t n, c
   return hipGetLastError();
 }
 
+// per-function medium probe (rene_medium_eval), layout in include/rene_hip.h
+__global__ void __launch_bounds__(64) medium_eval_kernel(SceneView S, uint32_t medium, uint32_t n, const float* rd3,
+                                                         const float* t_max, const float* wo3, const float* wi3,
+                                                         const uint32_t* seeds, float* out) {
+  uint32_t i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  MediumRec m = load_medium(S, medium);
+  f3 rd = mk3(rd3[3 * i], rd3[3 * i + 1], rd3[3 * i + 2]);
+  f3 wo = mk3(wo3[3 * i], wo3[3 * i + 1], wo3[3 * i + 2]), wi = mk3(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]);
+  float* o = out + 16 * (size_t)i;
+  const bool vac = m.type == RENE_MEDIUM_VACUUM;  // EnumMedium dispatch, medium.rs:180-208
+  f3 tr = vac ? splat(1.0f) : medium_tr(m, rd, t_max[i]);
+  Pcg rng = pcg_new(seeds[i]);
+  SampledMedium sm{false, splat(0.0f), splat(1.0f)};
+  if (!vac) sm = medium_sample(m, splat(0.0f), rd, t_max[i], rng);
+  f3 p = vac ? splat(0.0f) : medium_sample_p(m, wo, rng);
+  o[0] = tr.x; o[1] = tr.y; o[2] = tr.z; o[3] = vac ? 0.0f : medium_phase(m, wo, wi);
+  o[4] = sm.sampled ? 1.0f : 0.0f; o[5] = sm.position.x; o[6] = sm.position.y; o[7] = sm.position.z;
+  o[8] = sm.tr.x; o[9] = sm.tr.y; o[10] = sm.tr.z; o[11] = p.x; o[12] = p.y; o[13] = p.z;
+  o[14] = __uint_as_float(pcg_u32(rng)); o[15] = 0.0f;
+}
+
+hipError_t launch_medium_eval(const SceneView& S, uint32_t medium, uint32_t n, const float* rd3, const float* t_max,
+                              const float* wo3, const float* wi3, const uint32_t* seeds, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(medium_eval_kernel, dim3((n + 63) / 64), dim3(64), 0, st, S, medium, n, rd3, t_max, wo3, wi3, seeds, out);
+  return hipGetLastError();
+}
+
 // =================================================================================================
 // host-side dispatch
 // =================================================================================================
@@ -94,6 +122,7 @@ hipError_t launch_render(const LaunchConfig& cfg, const SceneView& S, const Rend
   constexpr uint32_t ALL = FEAT_SPHERES | FEAT_GENERAL_BSDF | FEAT_TEXTURES | FEAT_LIGHTS | FEAT_BACKGROUND | FEAT_MULTI_LOBE;
   constexpr uint32_t GEN1 = ALL & ~FEAT_MULTI_LOBE;
   const uint32_t f = cfg.features;
+  if (f & FEAT_VOLPATH) return launch_render_vol(cfg, S, P, st);   // kernels_vol.hip
   if (!(f & FEAT_SMALL)) return launch_render_bvh(cfg, S, P, st);  // kernels_bvh.hip
   if (!(f & (FEAT_SPHERES | FEAT_GENERAL_BSDF | FEAT_TEXTURES | FEAT_BACKGROUND | FEAT_MULTI_LOBE)))
     return launch_small<FEAT_LIGHTS | FEAT_SMALL, 1>(cfg, S, P, st);

@@ -1,0 +1,30 @@
+// kernels_vol.hip -- render kernels of the volumetric integrator (Integrator "volpath", lib.rs:477-803):
+// render_kernel with FEAT_VOLPATH, over the item loop (small scenes) or the while-while BVH traversal.
+// Separate translation unit so that it compiles in parallel with the path-integrator families.
+#include "device_code.inc"  // opens namespace rene
+
+template <uint32_t FEAT, int MAXL>
+static hipError_t launch_vol(const LaunchConfig& cfg, const SceneView& S, const RenderParams& P, hipStream_t st) {
+  static_assert(FEAT & FEAT_VOLPATH, "volpath family only");
+  size_t lds = (FEAT & FEAT_SMALL) ? 0 : (size_t)cfg.stack_depth * BLOCK * sizeof(uint32_t);
+  dim3 grid(cfg.grid), block(BLOCK);
+  bool count = (P.flags & RENE_FLAG_COUNTERS) != 0, aov = !(P.flags & RENE_FLAG_NO_AOV);
+  if (count || aov) hipLaunchKernelGGL((render_kernel<FEAT, MAXL, true, true>), grid, block, lds, st, S, P);
+  else hipLaunchKernelGGL((render_kernel<FEAT, MAXL, false, false>), grid, block, lds, st, S, P);
+  return hipGetLastError();
+}
+
+hipError_t launch_render_vol(const LaunchConfig& cfg, const SceneView& S, const RenderParams& P, hipStream_t st) {
+  constexpr uint32_t ALL = FEAT_SPHERES | FEAT_GENERAL_BSDF | FEAT_TEXTURES | FEAT_LIGHTS | FEAT_BACKGROUND | FEAT_MULTI_LOBE | FEAT_VOLPATH;
+  constexpr uint32_t GEN1 = ALL & ~FEAT_MULTI_LOBE;
+  const uint32_t f = cfg.features;
+  const bool small = (f & FEAT_SMALL) != 0;
+  if (!(f & (FEAT_SPHERES | FEAT_GENERAL_BSDF | FEAT_TEXTURES | FEAT_BACKGROUND | FEAT_MULTI_LOBE)))
+    return small ? launch_vol<FEAT_LIGHTS | FEAT_VOLPATH | FEAT_SMALL, 1>(cfg, S, P, st)
+                 : launch_vol<FEAT_LIGHTS | FEAT_VOLPATH, 1>(cfg, S, P, st);
+  if (!(f & FEAT_MULTI_LOBE))
+    return small ? launch_vol<GEN1 | FEAT_SMALL, 1>(cfg, S, P, st) : launch_vol<GEN1, 1>(cfg, S, P, st);
+  return small ? launch_vol<ALL | FEAT_SMALL, 5>(cfg, S, P, st) : launch_vol<ALL, 5>(cfg, S, P, st);
+}
+
+}  // namespace rene

@@ -714,6 +714,7 @@ struct rene_scene {
   std::vector<rene_texture> textures;
   std::vector<rene_area_light> area_lights;
   std::vector<rene_light> lights;
+  std::vector<rene_medium> mediums;
   std::vector<std::vector<float>> image_data;
   std::vector<rene_image> images;
 };
@@ -723,8 +724,9 @@ namespace {
 struct WorldState {  // scene.rs:66-78
   uint32_t material = 0;
   uint32_t area_light = 0;
+  uint32_t medium_interior = 0, medium_exterior = 0;  // current_medium_index, None == (0, 0)
   M4 ctm = M4::identity();
-  std::map<std::string, uint32_t> textures, materials;
+  std::map<std::string, uint32_t> textures, materials, mediums;
   std::map<std::string, std::vector<rene_instance>> objects;
   std::map<std::string, M4> coord_system;
 };
@@ -748,6 +750,9 @@ struct Builder {
     rene_area_light nul{};
     nul.type = RENE_AREA_LIGHT_NULL;
     sc.area_lights.push_back(nul);
+    rene_medium vacuum{};
+    vacuum.type = RENE_MEDIUM_VACUUM;
+    sc.mediums.push_back(vacuum);
     solid(1.0f, 1.0f, 1.0f);
   }
 
@@ -1104,7 +1109,17 @@ struct Builder {
           st.ctm = it->second;
           break;
         }
-        case World::MediumInterface: break;  // media only matter to the volpath integrator (out of scope)
+        case World::MediumInterface: {  // scene.rs:320-341; "" names the vacuum at index 0
+          auto find = [&](const std::string& n) -> uint32_t {
+            if (n.empty()) return 0u;
+            auto it = st.mediums.find(n);
+            if (it == st.mediums.end()) fail(RENE_ERR_INVALID_SCENE, "Unknown Medium " + n);
+            return it->second;
+          };
+          st.medium_interior = find(w.name);
+          st.medium_exterior = find(w.name2);
+          break;
+        }
         case World::Texture: {  // scene.rs:342-365; intermediate_scene.rs:769-833
           const Object& o = w.obj;
           rene_texture t{};
@@ -1203,12 +1218,25 @@ struct Builder {
       st.materials[o.t] = (uint32_t)sc.materials.size();
       st.material = (uint32_t)sc.materials.size();
       sc.materials.push_back(m);
-    } else if (o.kind == "MakeNamedMedium") {
-      // homogeneous media are volpath-only state; nothing to record for the path integrator
+    } else if (o.kind == "MakeNamedMedium") {  // intermediate_scene.rs:893-914; scene.rs:405-416
+      // every named medium is homogeneous whatever its "type" says; defaults are the reference's
+      rene_medium m{};
+      m.type = RENE_MEDIUM_HOMOGENEOUS;
+      float sigma_a[3] = {0.0011f, 0.0024f, 0.014f}, sigma_s[3] = {2.55f, 3.21f, 3.77f}, g = 0.0f;
+      get_rgb(o, "sigma_a", sigma_a);
+      get_rgb(o, "sigma_s", sigma_s);
+      get_float(o, "g", g);
+      std::copy(sigma_a, sigma_a + 3, m.v0);
+      m.v0[3] = g;
+      std::copy(sigma_s, sigma_s + 3, m.v1);
+      st.mediums[o.t] = (uint32_t)sc.mediums.size();
+      sc.mediums.push_back(m);
     } else if (o.kind == "Shape") {
       rene_instance inst{};
       inst.material_index = st.material;
       inst.area_light_index = st.area_light;
+      inst.interior_medium_index = st.medium_interior;
+      inst.exterior_medium_index = st.medium_exterior;
       if (o.t == "sphere") {  // scene.rs:418-436
         float radius = 1.0f;
         get_float(o, "radius", radius);
@@ -1350,6 +1378,8 @@ struct Builder {
     d.lights = sc.lights.data();
     d.n_images = (uint32_t)sc.images.size();
     d.images = sc.images.data();
+    d.n_mediums = (uint32_t)sc.mediums.size();
+    d.mediums = sc.mediums.data();
   }
 };
 

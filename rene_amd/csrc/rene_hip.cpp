@@ -65,7 +65,7 @@ struct rene_ctx {
   std::vector<void*> allocations;
   rene::SceneView view{};
   rene::LaunchConfig cfg{};
-  uint32_t width = 0, height = 0, tiles_x = 0, n_tiles = 0, n_work = 0, n_materials = 0;
+  uint32_t width = 0, height = 0, tiles_x = 0, n_tiles = 0, n_work = 0, n_materials = 0, n_mediums = 0;
   float* fb = nullptr;
   bool own_fb = false;
   size_t fb_floats = 0;
@@ -150,7 +150,8 @@ int rene_scene_pack_info(const rene_scene_desc* scene, rene_pack_info* out) {
                       ps.spheres.size() * sizeof(rene::Sphere) + ps.insts.size() * sizeof(rene::Inst) +
                       ps.emit_objects.size() * sizeof(rene::EmitObject) + ps.emit_tris.size() * sizeof(rene::EmitTri) +
                       ps.materials.size() * sizeof(rene::Material) + ps.textures.size() * sizeof(rene::Texture) +
-                      ps.lights.size() * sizeof(rene::Light) + ps.image_pool.size() * sizeof(float);
+                      ps.lights.size() * sizeof(rene::Light) + ps.image_pool.size() * sizeof(float) +
+                      ps.mediums.size() * sizeof(rene::Medium) + ps.inst_medium.size() * sizeof(rene::InstMedium);
   return RENE_OK;
 }
 
@@ -187,6 +188,7 @@ int rene_create(const rene_scene_desc* scene, const rene_opts* opts, rene_ctx** 
   c->width = ps.width;
   c->height = ps.height;
   c->n_materials = (uint32_t)ps.materials.size();
+  c->n_mediums = (uint32_t)ps.mediums.size();  // 0 unless the integrator is volpath
   struct Cleanup {
     std::unique_ptr<rene_ctx>& c;
     bool armed = true;
@@ -232,6 +234,8 @@ int rene_create(const rene_scene_desc* scene, const rene_opts* opts, rene_ctx** 
   UP(ps.materials, v.materials);
   UP(ps.textures, v.textures);
   UP(ps.lights, v.lights);
+  UP(ps.mediums, v.mediums);
+  UP(ps.inst_medium, v.inst_medium);
   UP(ps.images, v.images);
   UP(ps.image_pool, v.image_pool);
 #undef UP
@@ -506,6 +510,30 @@ int rene_bsdf_eval(rene_ctx* c, uint32_t material_index, size_t n, const float* 
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   for (int i = 0; i < 6; ++i) hipFree(d[i]);
   if (e != hipSuccess) return fail(RENE_ERR_DEVICE, std::string("rene_bsdf_eval: ") + hipGetErrorString(e));
+  return RENE_OK;
+}
+
+int rene_medium_eval(rene_ctx* c, uint32_t medium_index, size_t n, const float* rd3, const float* t_max,
+                     const float* wo3, const float* wi3, const uint32_t* seeds, float* out16) {
+  if (!c || (n && (!rd3 || !t_max || !wo3 || !wi3 || !seeds || !out16)))
+    return fail(RENE_ERR_INVALID_ARGUMENT, "rene_medium_eval: NULL argument");
+  if (medium_index >= c->n_mediums) return fail(RENE_ERR_INVALID_ARGUMENT, "medium_index out of range (media exist only under the volpath integrator)");
+  if (n == 0) return RENE_OK;
+  if (n > (1u << 24)) return fail(RENE_ERR_INVALID_ARGUMENT, "too many items in one batch");
+  HIP_TRY(hipSetDevice(c->device));
+  const size_t sizes[6] = {n * 12, n * 4, n * 12, n * 12, n * 4, n * 64};
+  const void* src[5] = {rd3, t_max, wo3, wi3, seeds};
+  void* d[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipError_t e = hipSuccess;
+  for (int i = 0; i < 6 && e == hipSuccess; ++i) e = hipMalloc(&d[i], sizes[i]);
+  for (int i = 0; i < 5 && e == hipSuccess; ++i) e = hipMemcpyAsync(d[i], src[i], sizes[i], hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess)
+    e = rene::launch_medium_eval(c->view, medium_index, (uint32_t)n, (const float*)d[0], (const float*)d[1],
+                                 (const float*)d[2], (const float*)d[3], (const uint32_t*)d[4], (float*)d[5], c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(out16, d[5], sizes[5], hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  for (int i = 0; i < 6; ++i) hipFree(d[i]);
+  if (e != hipSuccess) return fail(RENE_ERR_DEVICE, std::string("rene_medium_eval: ") + hipGetErrorString(e));
   return RENE_OK;
 }
 

@@ -367,10 +367,11 @@ int pack_scene(const rene_scene_desc* d, PackedScene& out, std::string& err) {
     err = "rene_scene_desc.struct_size mismatch (ABI skew)";
     return RENE_ERR_INVALID_ARGUMENT;
   }
-  if (d->integrator != RENE_INTEGRATOR_PATH) {
-    err = "Integrator volpath is not built yet (SURVEY section 8 f1)";
-    return RENE_ERR_UNSUPPORTED;
+  if (d->integrator != RENE_INTEGRATOR_PATH && d->integrator != RENE_INTEGRATOR_VOLPATH) {
+    err = "unknown integrator";
+    return RENE_ERR_INVALID_SCENE;
   }
+  if (d->n_mediums && !d->mediums) { err = "mediums is NULL"; return RENE_ERR_INVALID_ARGUMENT; }
   if (d->xresolution < 2 || d->yresolution < 2) {  // lib.rs:178-179 divides by W-1, H-1
     err = "film resolution must be at least 2x2";
     return RENE_ERR_INVALID_SCENE;
@@ -452,6 +453,23 @@ int pack_scene(const rene_scene_desc* d, PackedScene& out, std::string& err) {
       d->uniform.background_color[2] != 0.f)
     out.features |= FEAT_BACKGROUND;
 
+  // ---- media (scene.rs:111, 405-416).  An absent table means "just the vacuum". ----
+  const uint32_t n_mediums = d->n_mediums ? d->n_mediums : 1u;
+  if (d->integrator == RENE_INTEGRATOR_VOLPATH) {
+    out.features |= FEAT_VOLPATH;
+    out.mediums.resize(n_mediums);
+    std::memset(out.mediums.data(), 0, n_mediums * sizeof(Medium));
+    for (uint32_t i = 0; i < d->n_mediums; ++i) {
+      const rene_medium& m = d->mediums[i];
+      if (m.type > RENE_MEDIUM_HOMOGENEOUS) { err = "unknown medium type"; return RENE_ERR_INVALID_SCENE; }
+      for (int k = 0; k < 4; ++k)
+        if (!std::isfinite(m.v0[k]) || !std::isfinite(m.v1[k])) { err = "non-finite medium coefficient"; return RENE_ERR_INVALID_SCENE; }
+      std::memcpy(out.mediums[i].sa_g, m.v0, 16);
+      std::memcpy(out.mediums[i].ss_t, m.v1, 12);
+      std::memcpy(&out.mediums[i].ss_t[3], &m.type, 4);
+    }
+  }
+
   // ---- flatten instances to world space ----
   std::vector<Prim> prims, eprims;
   for (uint32_t ii = 0; ii < d->n_instances; ++ii) {
@@ -460,6 +478,11 @@ int pack_scene(const rene_scene_desc* d, PackedScene& out, std::string& err) {
       err = "instance references a material / area light out of range";
       return RENE_ERR_INVALID_SCENE;
     }
+    if (in.interior_medium_index >= n_mediums || in.exterior_medium_index >= n_mediums) {
+      err = "instance references a medium out of range";
+      return RENE_ERR_INVALID_SCENE;
+    }
+    if (out.features & FEAT_VOLPATH) out.inst_medium.push_back(InstMedium{in.interior_medium_index, in.exterior_medium_index});
     for (int k = 0; k < 12; ++k)
       if (!std::isfinite(in.matrix[k])) { err = "non-finite instance matrix"; return RENE_ERR_INVALID_SCENE; }
     Aff o2w = aff_from(in.matrix), w2o;

@@ -28,6 +28,8 @@ struct PackedScene {
   std::vector<Material> materials;
   std::vector<Texture> textures;
   std::vector<Light> lights;
+  std::vector<Medium> mediums;          // volpath only
+  std::vector<InstMedium> inst_medium;  // volpath only
   std::vector<ImageRef> images;
   std::vector<float> image_pool;
   rene_uniform uniform{};

@@ -82,7 +82,8 @@ def scene_to_pbrt(scene) -> str:
     back to pbrt text (used to round-trip the synthetic scenes through the loader in tests)."""
     from . import glam
     w2c = glam.to_cols(scene._world_to_camera)
-    out = ['Integrator "path"', "Transform [ " + " ".join(repr(float(v)) for v in w2c) + " ]",
+    out = ['Integrator "volpath"' if scene.integrator == abi.INTEGRATOR_VOLPATH else 'Integrator "path"',
+           "Transform [ " + " ".join(repr(float(v)) for v in w2c) + " ]",
            f'Film "image" "integer xresolution" [ {scene.film.xresolution} ] "integer yresolution" '
            f'[ {scene.film.yresolution} ] "string filename" [ "{scene.film.filename}" ]',
            f'Camera "perspective" "float fov" [ {scene._fov_deg!r} ]', "WorldBegin"]
@@ -92,12 +93,24 @@ def scene_to_pbrt(scene) -> str:
             raise ValueError("scene_to_pbrt only serialises Matte materials")
         c = scene.textures[m.u0[0]].v0
         out.append(f'\tMakeNamedMaterial "m{i}" "string type" [ "matte" ] "rgb Kd" [ {fl(c[:3])} ]')
+    for i, m in enumerate(scene.mediums[1:], start=1):
+        out.append(f'\tMakeNamedMedium "med{i}" "string type" [ "homogeneous" ] "rgb sigma_a" [ {fl(m.v0[:3])} ] '
+                   f'"rgb sigma_s" [ {fl(m.v1[:3])} ] "float g" [ {float(m.v0[3])!r} ]')
+    med = lambda k: f"med{k}" if k else ""
     for inst in scene.instances:
         lines = []
+        scoped = bool(inst.area_light_index)
+        if inst.interior_medium_index or inst.exterior_medium_index:
+            lines.append(f'MediumInterface "{med(inst.interior_medium_index)}" "{med(inst.exterior_medium_index)}"')
+            scoped = True
         if inst.area_light_index:
             L = scene.area_lights[inst.area_light_index].v0
             lines.append(f'AreaLightSource "diffuse" "rgb L" [ {fl(L[:3])} ]')
-        lines.append(f'NamedMaterial "m{inst.material_index}"')
+        if inst.material_index:
+            lines.append(f'NamedMaterial "m{inst.material_index}"')
+        else:  # the None material (a pure medium boundary), scene.rs:109
+            lines.append('Material "none"')
+            scoped = True
         if inst.shape == abi.SHAPE_TRIANGLE:
             mesh = scene.meshes[inst.mesh_index]
             v = mesh.vertices
@@ -105,7 +118,7 @@ def scene_to_pbrt(scene) -> str:
                          f' ] "point P" [ {fl(v[:, 0:3])} ] "normal N" [ {fl(v[:, 3:6])} ] "float uv" [ {fl(v[:, 6:8])} ]')
         else:
             raise ValueError("scene_to_pbrt only serialises triangle meshes")
-        if inst.area_light_index:
+        if scoped:
             out.append("\tAttributeBegin")
             out += ["\t\t" + l for l in lines]
             out.append("\tAttributeEnd")

@@ -66,6 +66,7 @@ class Scene:
     area_lights: list = field(default_factory=list)  # abi.AreaLight
     lights: list = field(default_factory=list)      # abi.Light
     images: list = field(default_factory=list)      # (h, w, 4) f32 arrays
+    mediums: list = field(default_factory=list)     # abi.Medium
 
     # ---- Scene::create prologue, scene.rs:104-116 ------------------------------------------------
     @staticmethod
@@ -73,6 +74,7 @@ class Scene:
         s = Scene()
         s.materials.append(abi.Material(type=abi.MATERIAL_NONE))
         s.area_lights.append(abi.AreaLight(type=abi.AREA_LIGHT_NULL))
+        s.mediums.append(abi.Medium(type=abi.MEDIUM_VACUUM))  # scene.rs:111
         s.add_texture_solid((1.0, 1.0, 1.0))  # default infinite-light texture
         return s
 
@@ -188,12 +190,21 @@ class Scene:
             self.background_texture = self.add_texture_image_map(image)
             self.background_matrix = glam.inverse(glam.identity() if ctm is None else ctm)
 
+    def add_medium_homogeneous(self, sigma_a, sigma_s, g: float = 0.0) -> int:
+        """EnumMedium::new_homogeneous, medium.rs:168-173 (MakeNamedMedium, scene.rs:405-416)."""
+        m = abi.Medium(type=abi.MEDIUM_HOMOGENEOUS)
+        m.v0[:] = [sigma_a[0], sigma_a[1], sigma_a[2], g]
+        m.v1[:] = [sigma_s[0], sigma_s[1], sigma_s[2], 0.0]
+        self.mediums.append(m)
+        return len(self.mediums) - 1
+
     # ---- shapes (scene.rs:417-456) ---------------------------------------------------------------
     def add_triangle_mesh(self, mesh: TriangleMesh, material: int, area_light: int = 0,
-                          ctm=None) -> int:
+                          ctm=None, interior: int = 0, exterior: int = 0) -> int:
         self.meshes.append(mesh)
         inst = abi.Instance(shape=abi.SHAPE_TRIANGLE, mesh_index=len(self.meshes) - 1,
-                            material_index=material, area_light_index=area_light)
+                            material_index=material, area_light_index=area_light,
+                            interior_medium_index=interior, exterior_medium_index=exterior)
         inst.matrix[:] = glam.affine_from_mat4(glam.identity() if ctm is None else ctm)
         self.instances.append(inst)
         return len(self.instances) - 1
@@ -205,10 +216,12 @@ class Scene:
         self.instances.append(inst)
         return len(self.instances) - 1
 
-    def add_sphere(self, radius: float, material: int, area_light: int = 0, ctm=None) -> int:
+    def add_sphere(self, radius: float, material: int, area_light: int = 0, ctm=None,
+                   interior: int = 0, exterior: int = 0) -> int:
         m = glam.mul(glam.identity() if ctm is None else ctm, glam.from_scale((radius,) * 3))
         inst = abi.Instance(shape=abi.SHAPE_SPHERE, mesh_index=-1, material_index=material,
-                            area_light_index=area_light)
+                            area_light_index=area_light, interior_medium_index=interior,
+                            exterior_medium_index=exterior)
         inst.matrix[:] = glam.affine_from_mat4(m)
         self.instances.append(inst)
         return len(self.instances) - 1
@@ -279,6 +292,7 @@ class PackedScene:
         d.n_area_lights, d.area_lights = len(s.area_lights), arr(abi.AreaLight, s.area_lights)
         d.n_lights, d.lights = len(s.lights), arr(abi.Light, s.lights)
         d.n_images, d.images = len(images), arr(abi.Image, images)
+        d.n_mediums, d.mediums = len(s.mediums), arr(abi.Medium, s.mediums)
         self.desc = d
         self.xres, self.yres = d.xresolution, d.yresolution
 

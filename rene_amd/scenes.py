@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from . import glam
+from . import abi, glam
 from .scene import Scene, TriangleMesh
 
 F32 = np.float32
@@ -89,6 +89,67 @@ def cornell_box(xres: int = 1024, yres: int = 1024) -> Scene:
     s.add_triangle_mesh(_quad([-0.24, 1.98, -0.22, 0.23, 1.98, -0.22, 0.23, 1.98, 0.16,
                                -0.24, 1.98, 0.16], (-8.74228e-08, -1, 1.86006e-07)),
                         mat["Light"], area_light=light)
+    return s
+
+
+# ---------------------------------------------------------------------------------------------------
+# volpath scenes.  The reference ships no scene that uses Integrator
+# "volpath" / MakeNamedMedium, so these are parity-test inputs of this repository: the Cornell box with a
+# thin fog filling the room and a dense cloud where the short box stood (nested media behind
+# None-material boundaries, lib.rs:768-779), and a BVH-sized scene with every volpath branch.
+# ---------------------------------------------------------------------------------------------------
+def _aabb(lo, hi) -> TriangleMesh:
+    """Axis-aligned box, outward vertex normals, 12 triangles (two coplanar per face)."""
+    (x0, y0, z0), (x1, y1, z1) = lo, hi
+    faces = [((-1, 0, 0), [(x0, y0, z0), (x0, y0, z1), (x0, y1, z1), (x0, y1, z0)]),
+             ((1, 0, 0), [(x1, y0, z0), (x1, y1, z0), (x1, y1, z1), (x1, y0, z1)]),
+             ((0, -1, 0), [(x0, y0, z0), (x1, y0, z0), (x1, y0, z1), (x0, y0, z1)]),
+             ((0, 1, 0), [(x0, y1, z0), (x0, y1, z1), (x1, y1, z1), (x1, y1, z0)]),
+             ((0, 0, -1), [(x0, y0, z0), (x0, y1, z0), (x1, y1, z0), (x1, y0, z0)]),
+             ((0, 0, 1), [(x0, y0, z1), (x1, y0, z1), (x1, y1, z1), (x0, y1, z1)])]
+    P, N, I = [], [], []
+    for n, q in faces:
+        b = len(P)
+        P += q
+        N += [n] * 4
+        I += [b, b + 1, b + 2, b, b + 2, b + 3]
+    return TriangleMesh.from_arrays(np.asarray(P, dtype=F32).reshape(-1), I, normals=N, uvs=_QUAD_UV * 6)
+
+
+def cornell_fog(xres: int = 1024, yres: int = 1024) -> Scene:
+    """Cornell box under Integrator "volpath": 48 triangles; a fog volume (sigma_t = 0.45) fills the
+    room below the light, a dense forward-scattering cloud (sigma_t ~ 6, g = 0.4) replaces the short
+    box; both are bounded by None-material boxes (MediumInterface inside AttributeBegin/End)."""
+    s = cornell_box(xres, yres)
+    s.integrator = abi.INTEGRATOR_VOLPATH
+    s.film.filename = "cornell-fog.png"
+    short = next(i for i, m in enumerate(s.meshes) if len(m.indices) == 36)  # the short box comes first
+    inst = next(i for i, it in enumerate(s.instances) if it.mesh_index == short)
+    fog = s.add_medium_homogeneous((0.02, 0.02, 0.03), (0.42, 0.42, 0.44), 0.0)
+    cloud = s.add_medium_homogeneous((0.3, 0.2, 0.1), (5.5, 5.8, 6.2), 0.4)
+    s.instances[inst].material_index = 0  # None: a pure medium boundary
+    s.instances[inst].interior_medium_index = cloud
+    s.instances[inst].exterior_medium_index = fog
+    s.add_triangle_mesh(_aabb((-0.995, 0.005, -0.995), (0.995, 1.9, 0.995)), 0, interior=fog, exterior=0)
+    return s
+
+
+def media_zoo(xres: int = 96, yres: int = 64) -> Scene:
+    """Every volpath branch in one BVH-sized scene: distant light through media (tr, lib.rs:359-409),
+    area emitters seen from inside media (tr_emit), glass and None boundaries around media, nested
+    spheres, anisotropic phase functions, textured surfaces, the infinite light."""
+    s = material_zoo(xres, yres)
+    s.integrator = abi.INTEGRATOR_VOLPATH
+    s.film.filename = "media-zoo.png"
+    milk = s.add_medium_homogeneous((0.0011, 0.0024, 0.014), (2.55, 3.21, 3.77), 0.0)  # the loader's defaults
+    smoke = s.add_medium_homogeneous((0.8, 0.8, 0.8), (1.2, 1.2, 1.2), -0.3)
+    haze = s.add_medium_homogeneous((0.01, 0.01, 0.01), (0.08, 0.09, 0.12), 0.7)
+    glass = s.add_glass(1.33)
+    s.add_sphere(0.7, glass, ctm=glam.from_translation((-1.6, 0.7, -2.2)), interior=milk)
+    s.add_sphere(0.8, 0, ctm=glam.from_translation((1.4, 0.8, -2.4)), interior=smoke, exterior=haze)
+    s.add_sphere(0.3, s.add_matte((0.8, 0.3, 0.2)), ctm=glam.from_translation((1.4, 0.8, -2.4)),
+                 interior=smoke, exterior=smoke)
+    s.add_triangle_mesh(_aabb((-5.5, 0.01, -4.5), (5.5, 3.6, 3.9)), 0, interior=haze, exterior=0)
     return s
 
 

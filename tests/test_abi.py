@@ -22,11 +22,12 @@ def test_header_is_plain_c_and_sizes_match_ctypes():
              "rene_material": abi.Material, "rene_texture": abi.Texture, "rene_area_light": abi.AreaLight,
              "rene_light": abi.Light, "rene_image": abi.Image, "rene_uniform": abi.Uniform,
              "rene_scene_desc": abi.SceneDesc, "rene_opts": abi.Opts, "rene_stats": abi.Stats,
-             "rene_hit": abi.Hit, "rene_pack_info": abi.PackInfo}
+             "rene_hit": abi.Hit, "rene_pack_info": abi.PackInfo, "rene_medium": abi.Medium}
     prog = '#include <stdio.h>\n#include "rene_hip.h"\nint main(void){\n'
     for n in names:
         prog += f'printf("{n} %zu\\n", sizeof({n}));\n'
     prog += 'printf("offset_instances %zu\\n", offsetof(rene_scene_desc, instances));\n'
+    prog += 'printf("offset_mediums %zu\\n", offsetof(rene_scene_desc, mediums));\n'
     prog += 'printf("offset_framebuffer %zu\\n", offsetof(rene_opts, framebuffer));\nreturn 0;}\n'
     with tempfile.TemporaryDirectory() as d:
         src = os.path.join(d, "t.c")
@@ -37,6 +38,7 @@ def test_header_is_plain_c_and_sizes_match_ctypes():
     for n, cls in names.items():
         assert int(out[n]) == C.sizeof(cls), n
     assert int(out["offset_instances"]) == abi.SceneDesc.instances.offset
+    assert int(out["offset_mediums"]) == abi.SceneDesc.mediums.offset
     assert int(out["offset_framebuffer"]) == abi.Opts.framebuffer.offset
 
 
@@ -109,8 +111,17 @@ def test_validation_errors(hip_lib):
     s.add_triangle_mesh(TriangleMesh.from_arrays([0, 0, 0, 1, 0, 0, 0, 1, 0], [0, 1, 2]), material=99)
     assert code(s) == -2  # material out of range
     s = _tiny()
+    s.integrator = 7
+    assert code(s) == -2  # only path (0) and volpath (1) exist, main.rs:520-523
+    s = _tiny()
     s.integrator = abi.INTEGRATOR_VOLPATH
-    assert code(s) == -4  # volpath: unsupported, not silently rendered as path
+    m = TriangleMesh.from_arrays([0, 0, 0, 1, 0, 0, 0, 1, 0], [0, 1, 2])
+    s.add_triangle_mesh(m, 0, interior=3)
+    assert code(s) == -2  # medium index out of range
+    s = _tiny()
+    s.integrator = abi.INTEGRATOR_VOLPATH
+    s.add_triangle_mesh(m, 0, interior=s.add_medium_homogeneous((1, 1, 1), (float("nan"), 1, 1)))
+    assert code(s) == -2  # non-finite coefficient
     s = _tiny(w=1, h=16)
     assert code(s) == -2  # W-1 division, lib.rs:178
     s = _tiny()
