@@ -16,6 +16,13 @@ def run(name, s, F, reps=3):
           f"B_alg/ray {abi.algorithmic_bytes(c)/c.rays:.0f}, features {api.pack_info(s).features}", flush=True)
     r.close()
 
+only = sys.argv[1] if len(sys.argv) > 1 else ""
+if only == "vol":
+    run("cornell-fog 1024x1024 (volpath)", scenes.cornell_fog(1024, 1024), 32)
+    s = scenes.cornell_box(1024, 1024); s.integrator = abi.INTEGRATOR_VOLPATH
+    run("cornell vacuum 1024x1024 (volpath)", s, 32)
+    run("media-zoo 1024x768 (volpath)", scenes.media_zoo(1024, 768), 16)
+    sys.exit(0)
 run("C2 cornell 1024x1024", scenes.cornell_box(1024, 1024), 64)
 run("C3 veach-mis 1024x1024", scenes.veach_mis(1024, 1024), 64)
 run("C3 veach-mis 1024x1024 (BVH)", scenes.veach_mis(1024, 1024), 64) if False else None
