@@ -10,10 +10,13 @@ persistent render kernel over every pixel this rank owns for `frames_per_step = 
 frames, so the K timed steps always render the full 1024 spp (a little more if K does not divide
 1024).  Inputs (scene tables, BVH, frame seeds) are resident in HBM before the timed region.
 
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL).  The image is cut into 32x32
-tiles dealt round-robin to the ranks (strong scaling: total work is fixed); ranks never talk while
-rendering; the one exchange step -- an RCCL gather of each rank's own tiles (1/N of the [3][H][W][4]
-f32 accumulation image per rank) onto rank 0 -- is inside the timed region.  value = rays of all ranks / max-over-ranks time.
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL).  Strong scaling: the job is still
+K steps = 1024 spp of the whole image; its K * frames_per_step frames are dealt to the ranks in N
+contiguous blocks (rene_amd.dist.frame_block), each rank renders its block in launches of at most
+frames_per_step frames, ranks never talk while rendering, and the one exchange step -- an RCCL reduce
+(sum) of the [3][H][W][4] f32 partial images onto rank 0 -- is inside the timed region.
+RENE_BENCH_SHARD=tiles selects the other cut (32x32 tiles round-robin + a gather of owned tiles: bit-
+identical to one GPU, but a rank's launches shrink with N).  value = rays of all ranks / max-over-ranks time.
 
 The JSON line also carries
   roofline     -- dominant kernel (render_kernel): algorithmic bytes per launch (SURVEY.md 8d cache-less
@@ -89,16 +92,31 @@ def main():
     scene = scenes.cornell_box(WIDTH, HEIGHT)
     packed = scene.to_desc()
 
+    by_tiles = os.environ.get("RENE_BENCH_SHARD", "frames") == "tiles"
+    t_rank, t_world = (rank, world) if by_tiles else (0, 1)
     fb = torch.zeros((3, HEIGHT, WIDTH, 4), dtype=torch.float32, device=f"cuda:{local}")
-    r = api.Renderer(packed, device=local, shard_mode=abi.SHARD_TILES, shard_rank=rank, shard_count=world,
+    r = api.Renderer(packed, device=local, shard_mode=abi.SHARD_TILES, shard_rank=t_rank, shard_count=t_world,
                      framebuffer_ptr=fb.data_ptr())
+    # this rank's launches: (first_frame, n_frames)
+    if by_tiles:
+        launches = [(k * F, F) for k in range(K)]
+    else:
+        lo, hi = rdist.frame_block(rank, world, K * F)
+        launches = [(f0, min(F, hi - f0)) for f0 in range(lo, hi, F)]
+
+    def exchange():
+        if world > 1:
+            if by_tiles:
+                rdist.gather_owned_tiles(fb, rank, world, dst=0)
+            else:
+                rdist.reduce_framebuffer(fb, dst=0)
 
     # ---- untimed: algorithmic bytes per ray from the kernel's own counters (same scene, seeds) ----
     # (counted over this build's BVH2 -- RENE_FLAG_FORCE_BVH -- so that the figure does not depend on
     # which intersection back end renders the scene: the small-scene item loop tests every item)
     cf = min(F, 8)
     with api.Renderer(packed, device=local, flags=abi.FLAG_COUNTERS | abi.FLAG_FORCE_BVH, shard_mode=abi.SHARD_TILES,
-                      shard_rank=rank, shard_count=world) as rc:
+                      shard_rank=t_rank, shard_count=t_world) as rc:
         rc.render(0, cf)
         cst = rc.stats()
     bytes_per_ray = abi.algorithmic_bytes(cst) / max(1, cst.rays)
@@ -107,9 +125,8 @@ def main():
     for k in range(Wm):
         r.render(k * F, F)
     r.sync()
-    if world > 1:
-        rdist.gather_owned_tiles(fb, rank, world, dst=0)
-        torch.cuda.synchronize()
+    exchange()
+    torch.cuda.synchronize()
     r.reset()
     fb.zero_()
 
@@ -121,11 +138,10 @@ def main():
 
     fence()
     t0 = time.perf_counter()
-    for k in range(K):
-        r.render(k * F, F)
+    for f0, nf in launches:
+        r.render(f0, nf)
     r.sync()
-    if world > 1:
-        rdist.gather_owned_tiles(fb, rank, world, dst=0)  # the one exchange step (RCCL gather over xGMI)
+    exchange()  # the one exchange step (RCCL over xGMI)
     fence()
     elapsed = time.perf_counter() - t0
 
@@ -152,7 +168,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"cornell-box {WIDTH}x{HEIGHT} @ {spp} spp", "width": WIDTH, "height": HEIGHT,
                        "spp": spp, "frames_per_step": F, "triangles": scene.n_triangles,
-                       "sharding": f"32x32 tiles round-robin over {n_gpus} GPU(s) + RCCL gather of owned tiles",
+                       "sharding": (f"32x32 tiles round-robin over {n_gpus} GPU(s) + RCCL gather of owned tiles" if by_tiles else
+                                    f"{K * F} frames in {n_gpus} contiguous block(s), one per GPU, + RCCL reduce of the partial images"),
                        "seed": abi.DEFAULT_SEED},
             "rays": total_rays, "rays_per_path": total_rays / (WIDTH * HEIGHT * spp),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

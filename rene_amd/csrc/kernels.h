@@ -10,7 +10,8 @@ namespace rene {
 struct LaunchConfig {
   uint32_t features = 0;     // FEAT_* of the scene
   uint32_t stack_depth = 16; // LDS traversal stack entries per lane
-  uint32_t grid = 0;         // workgroups of the persistent render launch
+  uint32_t grid = 0;         // workgroups of the persistent render launch (upper bound)
+  uint32_t cus = 0;          // compute units of the device
 };
 
 hipError_t launch_render(const LaunchConfig& cfg, const SceneView& S, const RenderParams& P, hipStream_t st);

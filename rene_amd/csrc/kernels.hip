@@ -106,13 +106,14 @@ hipError_t launch_medium_eval(const SceneView& S, uint32_t medium, uint32_t n, c
 // =================================================================================================
 // small-scene family (wave-coherent item loop): instantiated in this translation unit
 template <uint32_t FEAT, int MAXL>
-static hipError_t launch_small(const LaunchConfig& cfg, const SceneView& S, const RenderParams& P, hipStream_t st) {
+static hipError_t launch_small(const LaunchConfig& cfg, const SceneView& S, const RenderParams& P0, hipStream_t st) {
   static_assert(FEAT & FEAT_SMALL, "small family only");
   dim3 grid(cfg.grid), block(BLOCK);
-  bool count = (P.flags & RENE_FLAG_COUNTERS) != 0, aov = !(P.flags & RENE_FLAG_NO_AOV);
-  if (count) hipLaunchKernelGGL((render_kernel<FEAT, MAXL, true, true>), grid, block, 0, st, S, P);
-  else if (aov) hipLaunchKernelGGL((render_kernel<FEAT, MAXL, false, true>), grid, block, 0, st, S, P);
-  else hipLaunchKernelGGL((render_kernel<FEAT, MAXL, false, false>), grid, block, 0, st, S, P);
+  bool count = (P0.flags & RENE_FLAG_COUNTERS) != 0, aov = !(P0.flags & RENE_FLAG_NO_AOV);
+  RenderParams P = P0;
+  auto kernel = count ? render_kernel<FEAT, MAXL, true, true> : (aov ? render_kernel<FEAT, MAXL, false, true> : render_kernel<FEAT, MAXL, false, false>);
+  fit_grid(kernel, 0, cfg, P, grid);
+  hipLaunchKernelGGL(kernel, grid, block, 0, st, S, P);
   return hipGetLastError();
 }
 

@@ -4,13 +4,15 @@
 #include "device_code.inc"  // opens namespace rene
 
 template <uint32_t FEAT, int MAXL>
-static hipError_t launch_vol(const LaunchConfig& cfg, const SceneView& S, const RenderParams& P, hipStream_t st) {
+static hipError_t launch_vol(const LaunchConfig& cfg, const SceneView& S, const RenderParams& P0, hipStream_t st) {
   static_assert(FEAT & FEAT_VOLPATH, "volpath family only");
   size_t lds = (FEAT & FEAT_SMALL) ? 0 : (size_t)cfg.stack_depth * BLOCK * sizeof(uint32_t);
   dim3 grid(cfg.grid), block(BLOCK);
-  bool count = (P.flags & RENE_FLAG_COUNTERS) != 0, aov = !(P.flags & RENE_FLAG_NO_AOV);
-  if (count || aov) hipLaunchKernelGGL((render_kernel<FEAT, MAXL, true, true>), grid, block, lds, st, S, P);
-  else hipLaunchKernelGGL((render_kernel<FEAT, MAXL, false, false>), grid, block, lds, st, S, P);
+  bool count = (P0.flags & RENE_FLAG_COUNTERS) != 0, aov = !(P0.flags & RENE_FLAG_NO_AOV);
+  RenderParams P = P0;
+  auto kernel = (count || aov) ? render_kernel<FEAT, MAXL, true, true> : render_kernel<FEAT, MAXL, false, false>;
+  fit_grid(kernel, lds, cfg, P, grid);
+  hipLaunchKernelGGL(kernel, grid, block, lds, st, S, P);
   return hipGetLastError();
 }
 

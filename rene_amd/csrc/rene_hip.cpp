@@ -264,7 +264,8 @@ int rene_create(const rene_scene_desc* scene, const rene_opts* opts, rene_ctx** 
   c->cfg.stack_depth = stack;
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, o.device));
-  c->cfg.grid = (uint32_t)prop.multiProcessorCount * 8u;  // persistent launch; surplus blocks find no work
+  c->cfg.grid = (uint32_t)prop.multiProcessorCount * 8u;  // persistent launch: upper bound, clamped to the co-resident blocks at launch
+  c->cfg.cus = (uint32_t)prop.multiProcessorCount;
   if (const char* e = std::getenv("RENE_BLOCKS_PER_CU")) {  // tuning knob (experiments only)
     int b = std::atoi(e);
     if (b > 0 && b <= 64) c->cfg.grid = (uint32_t)prop.multiProcessorCount * (uint32_t)b;
@@ -373,8 +374,14 @@ int rene_render(rene_ctx* c, uint32_t first_frame, uint32_t n_frames) {
   if (const char* e = std::getenv("RENE_READY_MIN")) P.ready_min = (uint32_t)std::max(1, std::atoi(e));  // tuning knobs
   if (const char* e = std::getenv("RENE_LEAF_MIN")) P.leaf_min = (uint32_t)std::max(1, std::atoi(e));
   rene::LaunchConfig cfg = c->cfg;
-  uint32_t blocks_needed = (c->n_work + rene::render_block_size() - 1) / rene::render_block_size();
+  // launch no more lanes than there are work items; hand items out in batches small enough that every
+  // launched wave gets some (a tile shard of a small image has fewer items than the chip has lanes)
+  const uint32_t total_items = P.two_level ? 2u * c->n_work : c->n_work;
+  uint32_t blocks_needed = (total_items + rene::render_block_size() - 1) / rene::render_block_size();
   cfg.grid = std::max(1u, std::min(cfg.grid, blocks_needed));
+  const uint32_t waves = cfg.grid * (uint32_t)(rene::render_block_size() / 64);
+  P.work_batch = 128;
+  while (P.work_batch > 16 && (uint64_t)P.work_batch * waves * 2u > total_items) P.work_batch >>= 1;
   hipEventRecord(pend.start, c->stream);
   e = rene::launch_render(cfg, c->view, P, c->stream);
   hipEventRecord(pend.stop, c->stream);

@@ -1,10 +1,14 @@
 """Multi-GPU plumbing: one process per GPU, `torch.distributed` (backend "nccl" = RCCL over xGMI).
 
-The render path shards by construction -- a pixel's result depends only on (x, y, frame seed)
+The render path shards by construction -- a sample depends only on (x, y, frame seed)
 (rene-shader/src/lib.rs:174-176) -- so ranks never exchange data while rendering.  The single
-exchange step is the sum of the per-rank framebuffers at the end: every
-pixel is owned by exactly one rank under tile sharding, so the reduce adds zeros to the owner's
-value and the result is bit-identical to a single-GPU render.
+exchange step is the sum of the per-rank framebuffers at the end.  Two ways
+to cut the job: by frames (`frame_block`: every rank renders the whole image for a block of frames;
+the exchange is a reduce of the whole image; the sum differs from a single-GPU render only in fp32
+summation order) or by tiles (`gather_owned_tiles`: every pixel has exactly one owner, the exchange
+moves 1/N of the image per rank and the result is bit-identical to a single-GPU render, but a rank's
+launches shrink with N).  bench.py uses frames: at 1024^2 a tile shard of 8 has fewer pixels than the
+GPU has lanes.
 """
 from __future__ import annotations
 
@@ -81,9 +85,25 @@ def gather_owned_tiles(fb, rank: int, world: int, dst: int = 0):
     return fb
 
 
+def frame_block(rank: int, world: int, total_frames: int) -> tuple[int, int]:
+    """Frame sharding in contiguous blocks: rank r renders frames [r * T / world, (r + 1) * T / world)
+    of the whole image (sizes differ by at most one frame).  Samples are independent given their frame
+    seed (lib.rs:174-176, 512-514), so the ranks never talk while rendering; the exchange step is the
+    sum of the partial images (`reduce_framebuffer`).  Blocks, not round robin: a rank then renders
+    its share in launches as large as a single GPU's (a launch has a fixed cost of ~0.35 ms: the
+    longest single path of its last frames)."""
+    world = max(1, world)
+    return rank * total_frames // world, (rank + 1) * total_frames // world
+
+
 def reduce_framebuffer(fb, dst: int = 0):
     """Sum the per-rank accumulation images onto rank `dst` (ncclReduce over xGMI on GPUs)."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.reduce(fb, dst=dst, op=dist.ReduceOp.SUM)
+        if fb.is_cuda and dist.get_backend() == "gloo":  # rehearsal backend: reduce through the host
+            host = fb.cpu()
+            dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM)
+            fb.copy_(host)
+        else:
+            dist.reduce(fb, dst=dst, op=dist.ReduceOp.SUM)
     return fb

@@ -108,3 +108,53 @@ def test_tile_owner_map_partitions_image():
         assert counts.sum() == w * h
         if w * h >= 1024 * 1024:
             assert counts.max() / counts.min() < 1.15  # interleaved tiles balance the pixel load
+
+
+def _frame_worker(rank, world, port, q, total):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    from rene_amd import dist as rdist, scenes
+    from oracle import oracle
+    rdist.init_process_group("gloo")
+    o = oracle.Oracle(scenes.cornell_box(64, 48))
+    lo, hi = rdist.frame_block(rank, world, total)
+    for f0 in range(lo, hi, 2):  # launches of at most 2 frames, like bench.py's frames_per_step
+        o.render(f0, min(2, hi - f0), threads=1)
+    fb = torch.from_numpy(np.stack([o.download(l, 4) for l in range(3)]))
+    rdist.reduce_framebuffer(fb, dst=0)
+    dist.barrier()
+    if rank == 0:
+        q.put(fb.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,total", [(2, 7), (3, 8)])
+def test_frame_block_reduce_equals_single_up_to_summation_order(world, total):
+    """bench.py's N > 1 cut: contiguous frame blocks + one reduce of the partial images."""
+    import torch.multiprocessing as mp
+    from rene_amd import scenes
+    from rene_amd.dist import frame_block
+    from oracle import oracle
+    blocks = [frame_block(r, world, total) for r in range(world)]
+    assert blocks[0][0] == 0 and blocks[-1][1] == total
+    assert all(blocks[i][1] == blocks[i + 1][0] for i in range(world - 1))
+    assert max(b - a for a, b in blocks) - min(b - a for a, b in blocks) <= 1
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_frame_worker, args=(r, world, port, q, total)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    o = oracle.Oracle(scenes.cornell_box(64, 48))
+    o.render(0, total, threads=1)
+    want = np.stack([o.download(l, 4) for l in range(3)])
+    # every sample is the same; only the order of the fp32 additions differs (per-rank partial sums)
+    np.testing.assert_allclose(got, want, rtol=2e-6, atol=1e-6)
+    assert not np.array_equal(got[0], np.zeros_like(got[0]))
