@@ -118,13 +118,18 @@ struct InstMedium {  // IndexData::{interior,exterior}_medium_index, lib.rs:108-
 // lanes test the same item, so the record comes through the scalar cache into SGPRs and there is no
 // traversal divergence at all (a BVH over 36 triangles ran at ~30 % SIMD efficiency).  Two triangles
 // of one instance that form a parallelogram are merged into one item (half the tests).
-//   q[0..2] = O, q[3..5] = a, q[6..8] = b:   X(s,t) = O + s a + t b
-//   q[9]    = bits(kind): 0 triangle (s + t <= 1), 1 parallelogram (s, t <= 1), 2 sphere
-//   q[10]   = bits(slot of the triangle covering s + t <= 1)   (sphere: its slot)
-//   q[11]   = bits(slot of the triangle covering s + t  > 1)
-//   q[12]   = bits(perm1), q[13] = bits(perm2): for each triangle, which of the three generic corner
-//             weights is its u (bits 1..0) and its v (bits 3..2); corners are (O, O+a, O+b) with weights
-//             (1-s-t, s, t) for the first triangle and (O+a+b, O+a, O+b) with (s+t-1, 1-t, 1-s) for the second
+// An item is the surface X(s,r) = O + s a + r b, stored in the form the loop evaluates fastest -- the
+// plane first, then the hit point's coordinates in the reciprocal basis of (a, b):
+//   q[0..3]  = n = a x b (not normalised), n . O        ray parameter t = (n.O - n.o) / (n.d)
+//   q[4..11] = u'.x v'.x  u'.y v'.y  u'.z v'.z  -O.u' -O.v'   with u' = (b x n)/|n|^2, v' = (n x a)/|n|^2,
+//              so that for P = o + t d:  s = P.u' - O.u',  r = P.v' - O.v'   (interleaved for v_pk_fma_f32)
+//   q[12]    = bits(kind): 0 triangle (s + r <= 1), 1 parallelogram (s, r <= 1), 2 sphere
+//   q[13]    = bits(slot of the triangle covering s + r <= 1)   (sphere: its slot)
+//   q[14]    = bits(slot of the triangle covering s + r  > 1)
+//   q[15]    = bits(perm1 | perm2 << 8): for each triangle, which of the three generic corner weights is
+//              its u (bits 1..0) and its v (bits 3..2); corners are (O, O+a, O+b) with weights
+//              (1-s-r, s, r) for the first triangle and (O+a+b, O+a, O+b) with (s+r-1, 1-r, 1-s) for the second
+// A degenerate item (n = 0) is stored as all zeros: n.d = 0 rejects every ray.
 struct SmallItem {
   float q[16];
 };

@@ -112,8 +112,9 @@ static hipError_t launch_small(const LaunchConfig& cfg, const SceneView& S, cons
   bool count = (P0.flags & RENE_FLAG_COUNTERS) != 0, aov = !(P0.flags & RENE_FLAG_NO_AOV);
   RenderParams P = P0;
   auto kernel = count ? render_kernel<FEAT, MAXL, true, true> : (aov ? render_kernel<FEAT, MAXL, false, true> : render_kernel<FEAT, MAXL, false, false>);
-  fit_grid(kernel, 0, cfg, P, grid);
-  hipLaunchKernelGGL(kernel, grid, block, 0, st, S, P);
+  static const size_t lds_pad = std::getenv("RENE_LDS_PAD") ? (size_t)std::atoi(std::getenv("RENE_LDS_PAD")) : 0;  // occupancy experiments
+  fit_grid(kernel, lds_pad, cfg, P, grid);
+  hipLaunchKernelGGL(kernel, grid, block, lds_pad, st, S, P);
   return hipGetLastError();
 }
 

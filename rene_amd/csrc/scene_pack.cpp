@@ -287,16 +287,29 @@ void build_small_items(BuiltAccel& acc) {
     return std::fabs(a.x - b.x) <= tol && std::fabs(a.y - b.y) <= tol && std::fabs(a.z - b.z) <= tol;
   };
   std::vector<char> used(n, 0);
+  // plane + reciprocal-basis form of X(s,r) = O + s a + r b (device_scene.h), evaluated in double
+  auto surface = [](SmallItem& it, V3 O, V3 a, V3 b) {
+    const double ax = a.x, ay = a.y, az = a.z, bx = b.x, by = b.y, bz = b.z, ox = O.x, oy = O.y, oz = O.z;
+    const double nx = ay * bz - az * by, ny = az * bx - ax * bz, nz = ax * by - ay * bx;
+    const double n2 = nx * nx + ny * ny + nz * nz;
+    if (!(n2 > 0.0) || !std::isfinite(n2)) return;  // degenerate: stays all zero, never hit
+    const double ux = (by * nz - bz * ny) / n2, uy = (bz * nx - bx * nz) / n2, uz = (bx * ny - by * nx) / n2;
+    const double vx = (ny * az - nz * ay) / n2, vy = (nz * ax - nx * az) / n2, vz = (nx * ay - ny * ax) / n2;
+    it.q[0] = (float)nx; it.q[1] = (float)ny; it.q[2] = (float)nz; it.q[3] = (float)(nx * ox + ny * oy + nz * oz);
+    it.q[4] = (float)ux; it.q[5] = (float)vx; it.q[6] = (float)uy; it.q[7] = (float)vy;
+    it.q[8] = (float)uz; it.q[9] = (float)vz;
+    it.q[10] = (float)-(ux * ox + uy * oy + uz * oz);
+    it.q[11] = (float)-(vx * ox + vy * oy + vz * oz);
+  };
   auto emit_tri = [&](size_t s) {
     SmallItem it;
     std::memset(&it, 0, sizeof(it));
     const float* q = acc.isect[s].q;
-    for (int k = 0; k < 9; ++k) it.q[k] = q[k];  // O = p0, a = e1, b = e2: identical operands to the BVH path
-    it.q[9] = bits_to_float(t[s].sphere ? SMALL_SPHERE : SMALL_TRIANGLE);
-    it.q[10] = bits_to_float((uint32_t)s);
-    it.q[11] = bits_to_float((uint32_t)s);
-    it.q[12] = bits_to_float(1u | (2u << 2));  // u = weight of O+a, v = weight of O+b
-    it.q[13] = bits_to_float(1u | (2u << 2));
+    if (!t[s].sphere) surface(it, V3{q[0], q[1], q[2]}, V3{q[3], q[4], q[5]}, V3{q[6], q[7], q[8]});  // O = p0, a = e1, b = e2
+    it.q[12] = bits_to_float(t[s].sphere ? SMALL_SPHERE : SMALL_TRIANGLE);
+    it.q[13] = bits_to_float((uint32_t)s);
+    it.q[14] = bits_to_float((uint32_t)s);
+    it.q[15] = bits_to_float((1u | (2u << 2)) * 0x101u);  // u = weight of O+a, v = weight of O+b
     acc.items.push_back(it);
   };
   for (size_t i = 0; i < n; ++i) {
@@ -326,18 +339,14 @@ void build_small_items(BuiltAccel& acc) {
       if (!close(lhs, rhs, tol)) continue;
       SmallItem it;
       std::memset(&it, 0, sizeof(it));
-      V3 a = sub(X, Z1), b = sub(Y, Z1);
-      it.q[0] = Z1.x; it.q[1] = Z1.y; it.q[2] = Z1.z;
-      it.q[3] = a.x; it.q[4] = a.y; it.q[5] = a.z;
-      it.q[6] = b.x; it.q[7] = b.y; it.q[8] = b.z;
-      it.q[9] = bits_to_float(SMALL_QUAD);
-      it.q[10] = bits_to_float((uint32_t)i);
-      it.q[11] = bits_to_float((uint32_t)j);
+      surface(it, Z1, sub(X, Z1), sub(Y, Z1));
+      it.q[12] = bits_to_float(SMALL_QUAD);
+      it.q[13] = bits_to_float((uint32_t)i);
+      it.q[14] = bits_to_float((uint32_t)j);
       // generic corner index (0 = O / far corner, 1 = X, 2 = Y) of each triangle's v1 and v2
       auto corner_i = [&](int v) { return v == zi ? 0u : (v == xi ? 1u : 2u); };
       auto corner_j = [&](int v) { return v == zj ? 0u : (v == mi[xi] ? 1u : 2u); };
-      it.q[12] = bits_to_float(corner_i(1) | (corner_i(2) << 2));
-      it.q[13] = bits_to_float(corner_j(1) | (corner_j(2) << 2));
+      it.q[15] = bits_to_float((corner_i(1) | (corner_i(2) << 2)) | ((corner_j(1) | (corner_j(2) << 2)) << 8));
       acc.items.push_back(it);
       used[j] = 1;
       merged = true;
