@@ -123,7 +123,8 @@ struct InstMedium {  // IndexData::{interior,exterior}_medium_index, lib.rs:108-
 //   q[0..3]  = n = a x b (not normalised), n . O        ray parameter t = (n.O - n.o) / (n.d)
 //   q[4..11] = u'.x v'.x  u'.y v'.y  u'.z v'.z  -O.u' -O.v'   with u' = (b x n)/|n|^2, v' = (n x a)/|n|^2,
 //              so that for P = o + t d:  s = P.u' - O.u',  r = P.v' - O.v'   (interleaved for v_pk_fma_f32)
-//   q[12]    = bits(kind): 0 triangle (s + r <= 1), 1 parallelogram (s, r <= 1), 2 sphere
+//   q[12]    = kind as a float (SMALL_KIND_*): 1 triangle (s + r <= 1), 0 parallelogram (s, r <= 1), 2 sphere;
+//              for the first two it is the coefficient c of the inside test  1 - s - c r >= 0, 1 - r - c s >= 0
 //   q[13]    = bits(slot of the triangle covering s + r <= 1)   (sphere: its slot)
 //   q[14]    = bits(slot of the triangle covering s + r  > 1)
 //   q[15]    = bits(perm1 | perm2 << 8): for each triangle, which of the three generic corner weights is
@@ -134,7 +135,7 @@ struct SmallItem {
   float q[16];
 };
 constexpr uint32_t SMALL_MAX_ITEMS = 64;
-enum : uint32_t { SMALL_TRIANGLE = 0, SMALL_QUAD = 1, SMALL_SPHERE = 2 };
+constexpr float SMALL_KIND_QUAD = 0.0f, SMALL_KIND_TRIANGLE = 1.0f, SMALL_KIND_SPHERE = 2.0f;
 
 // one traversable structure
 struct Accel {

@@ -13,6 +13,7 @@
 // Integrator parameters are ignored (scene.rs:120-128).
 // Not supported (returns RENE_ERR_UNSUPPORTED, never a silent fallback): blackbody / spectrum
 // colours, loopsubdiv, EXR and LDR image files (out of scope).
+#include <zlib.h>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -770,11 +771,125 @@ struct Builder {
     return it->second;
   }
 
-  // ---- images: PFM only (pfm_parser.rs:10-61; load_image intermediate_scene.rs:631-677) ----
+  // ---- LDR images: load_image's fall-through branch (intermediate_scene.rs:657-675) decodes with the
+  // `image` crate (0.24.1, absent from /root/reference) and stores, per pixel of DynamicImage::pixels()
+  // (RGBA8), inverse_gamma_correct(c / 255) for r, g, b (intermediate_scene.rs:616-622) and a / 255.
+  // Restated here for PNG (RFC 2083: zlib stream + the five scanline filters), 8 bits per sample, not
+  // interlaced; grey -> r = g = b, missing alpha -> 255, like the crate's to-RGBA8 conversion.
+  static float inverse_gamma_correct(float v) {
+    return v <= 0.04045f ? v / 12.92f : std::pow((v + 0.055f) / 1.055f, 2.4f);
+  }
+  uint32_t load_png(const std::string& path, const std::string& file) {
+    std::string data = read_file(path);
+    static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    auto bad = [&](const char* why) { fail(RENE_ERR_IO, std::string("PNG decode error (") + why + "): " + file); };
+    if (data.size() < 8 || std::memcmp(data.data(), sig, 8) != 0) bad("signature");
+    auto be32 = [&](size_t p) {
+      return ((uint32_t)(unsigned char)data[p] << 24) | ((uint32_t)(unsigned char)data[p + 1] << 16) |
+             ((uint32_t)(unsigned char)data[p + 2] << 8) | (uint32_t)(unsigned char)data[p + 3];
+    };
+    uint32_t w = 0, h = 0, depth = 0, ctype = 0, interlace = 0;
+    std::string idat;
+    std::vector<unsigned char> plte, trns;
+    bool end = false;
+    for (size_t p = 8; p + 12 <= data.size() && !end;) {
+      uint32_t len = be32(p);
+      std::string type = data.substr(p + 4, 4);
+      if (p + 12 + (size_t)len > data.size()) bad("truncated chunk");
+      const char* body = data.data() + p + 8;
+      if (type == "IHDR") {
+        if (len != 13) bad("IHDR");
+        w = be32(p + 8); h = be32(p + 12);
+        depth = (unsigned char)body[8]; ctype = (unsigned char)body[9]; interlace = (unsigned char)body[12];
+      } else if (type == "PLTE") plte.assign(body, body + len);
+      else if (type == "tRNS") trns.assign(body, body + len);
+      else if (type == "IDAT") idat.append(body, len);
+      else if (type == "IEND") end = true;
+      p += 12 + (size_t)len;
+    }
+    if (!w || !h || idat.empty()) bad("no image data");
+    const bool packed = depth < 8 && (depth == 1 || depth == 2 || depth == 4) && (ctype == 0 || ctype == 3);
+    if (depth != 8 && !packed) unsupported("PNG with " + std::to_string(depth) + " bits per sample (" + file + ")");
+    if (interlace) unsupported("interlaced PNG (" + file + ")");
+    uint32_t ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+    if (!ch) bad("colour type");
+    if ((uint64_t)w * h > (1ull << 28)) bad("too large");
+    const size_t stride = ((size_t)w * ch * depth + 7) / 8;  // bytes per scanline
+    const size_t bpp = std::max<size_t>(1, (size_t)ch * depth / 8);  // filter distance, RFC 2083 section 6.2
+    std::vector<unsigned char> raw((stride + 1) * h);
+    uLongf out_len = (uLongf)raw.size();
+    if (uncompress(raw.data(), &out_len, reinterpret_cast<const Bytef*>(idat.data()), (uLong)idat.size()) != Z_OK ||
+        out_len != raw.size())
+      bad("zlib stream");
+    std::vector<unsigned char> px(stride * h);
+    for (uint32_t y = 0; y < h; ++y) {  // un-filter, RFC 2083 section 6
+      const unsigned char* in = raw.data() + (stride + 1) * y;
+      unsigned char* cur = px.data() + stride * y;
+      const unsigned char* up = y ? cur - stride : nullptr;
+      const unsigned filter = in[0];
+      if (filter > 4) bad("filter type");
+      for (size_t i = 0; i < stride; ++i) {
+        int a = i >= bpp ? cur[i - bpp] : 0, b = up ? up[i] : 0, c = (up && i >= bpp) ? up[i - bpp] : 0, pred = 0;
+        switch (filter) {
+          case 1: pred = a; break;
+          case 2: pred = b; break;
+          case 3: pred = (a + b) / 2; break;
+          case 4: {
+            int pa = std::abs(b - c), pb = std::abs(a - c), pc = std::abs(a + b - 2 * c);
+            pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+            break;
+          }
+          default: break;
+        }
+        cur[i] = (unsigned char)(in[1 + i] + pred);
+      }
+    }
+    std::vector<float> rgba((size_t)w * h * 4);
+    if (packed) {  // 1 / 2 / 4-bit samples, most significant first; grey levels scale to 0..255
+      std::vector<unsigned char> wide((size_t)w * h);
+      const unsigned maxv = (1u << depth) - 1u;
+      for (uint32_t y = 0; y < h; ++y)
+        for (uint32_t x = 0; x < w; ++x) {
+          const size_t bit = (size_t)x * depth;
+          unsigned v = (px[stride * y + bit / 8] >> (8 - depth - bit % 8)) & maxv;
+          wide[(size_t)y * w + x] = (unsigned char)(ctype == 0 ? v * 255u / maxv : v);
+        }
+      px.swap(wide);
+    }
+    for (size_t i = 0; i < (size_t)w * h; ++i) {
+      const unsigned char* s = px.data() + i * ch;
+      unsigned r, g, b, a = 255;
+      if (ctype == 3) {
+        if ((size_t)s[0] * 3 + 2 >= plte.size()) bad("palette index");
+        r = plte[s[0] * 3]; g = plte[s[0] * 3 + 1]; b = plte[s[0] * 3 + 2];
+        if (s[0] < trns.size()) a = trns[s[0]];
+      } else if (ch <= 2) {
+        r = g = b = s[0];
+        if (ch == 2) a = s[1];
+      } else {
+        r = s[0]; g = s[1]; b = s[2];
+        if (ch == 4) a = s[3];
+      }
+      rgba[i * 4 + 0] = inverse_gamma_correct((float)r / 255.0f);
+      rgba[i * 4 + 1] = inverse_gamma_correct((float)g / 255.0f);
+      rgba[i * 4 + 2] = inverse_gamma_correct((float)b / 255.0f);
+      rgba[i * 4 + 3] = (float)a / 255.0f;
+    }
+    sc.image_data.push_back(std::move(rgba));
+    rene_image im{};
+    im.rgba = sc.image_data.back().data();
+    im.width = w;
+    im.height = h;
+    sc.images.push_back(im);
+    return (uint32_t)sc.images.size() - 1;
+  }
+
+  // ---- HDR images: PFM (pfm_parser.rs:10-61; load_image intermediate_scene.rs:631-677) ----
   uint32_t load_image(const std::string& file) {
     std::string path = join_path(base_dir, file);
     size_t dot = path.rfind('.');
     std::string ext = dot == std::string::npos ? "" : path.substr(dot + 1);
+    if (ext == "png") return load_png(path, file);
     if (ext != "pfm") unsupported("image format ." + ext + " (" + file + ")");
     std::string data = read_file(path);
     // header: "PF\n<w> <h>\n<scale>\n" then rows bottom-to-top; negative scale = little endian

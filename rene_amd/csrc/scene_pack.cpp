@@ -306,7 +306,7 @@ void build_small_items(BuiltAccel& acc) {
     std::memset(&it, 0, sizeof(it));
     const float* q = acc.isect[s].q;
     if (!t[s].sphere) surface(it, V3{q[0], q[1], q[2]}, V3{q[3], q[4], q[5]}, V3{q[6], q[7], q[8]});  // O = p0, a = e1, b = e2
-    it.q[12] = bits_to_float(t[s].sphere ? SMALL_SPHERE : SMALL_TRIANGLE);
+    it.q[12] = t[s].sphere ? SMALL_KIND_SPHERE : SMALL_KIND_TRIANGLE;
     it.q[13] = bits_to_float((uint32_t)s);
     it.q[14] = bits_to_float((uint32_t)s);
     it.q[15] = bits_to_float((1u | (2u << 2)) * 0x101u);  // u = weight of O+a, v = weight of O+b
@@ -340,7 +340,7 @@ void build_small_items(BuiltAccel& acc) {
       SmallItem it;
       std::memset(&it, 0, sizeof(it));
       surface(it, Z1, sub(X, Z1), sub(Y, Z1));
-      it.q[12] = bits_to_float(SMALL_QUAD);
+      it.q[12] = SMALL_KIND_QUAD;
       it.q[13] = bits_to_float((uint32_t)i);
       it.q[14] = bits_to_float((uint32_t)j);
       // generic corner index (0 = O / far corner, 1 = X, 2 = Y) of each triangle's v1 and v2

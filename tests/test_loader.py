@@ -282,6 +282,50 @@ def test_include_ply_pfm(tmp_path, hip_lib):
     assert d.uniform.background_texture == d.n_textures - 1 and list(d.uniform.background_color[:3]) == [1, 1, 1]
 
 
+def test_png_image_textures(tmp_path, hip_lib):
+    """load_image's LDR branch (intermediate_scene.rs:657-675): RGBA8 pixels -> inverse_gamma_correct(c / 255)
+    for r, g, b and a / 255, rows top first.  Files written with PIL (an independent encoder that picks the
+    scanline filter per row), colour types grey / grey+alpha / RGB / RGBA / palette."""
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    h, w = 13, 17
+    smooth = (np.add.outer(np.arange(h) * 9, np.arange(w) * 5)[..., None] + np.array([0, 40, 90, 140])) % 256
+    noise = rng.integers(0, 256, (h, w, 4))
+    rgba = np.where((np.arange(h) % 2 == 0)[:, None, None], smooth, noise).astype(np.uint8)  # rows favour different filters
+    cases = {"rgba.png": Image.fromarray(rgba, "RGBA"), "rgb.png": Image.fromarray(rgba[..., :3], "RGB"),
+             "grey.png": Image.fromarray(rgba[..., 0], "L"), "la.png": Image.fromarray(rgba[..., [0, 3]], "LA"),
+             "pal.png": Image.fromarray(rgba[..., :3], "RGB").quantize(16)}
+    expect = {}
+    for name, im in cases.items():
+        im.save(tmp_path / name)
+        expect[name] = np.asarray(Image.open(tmp_path / name).convert("RGBA"), dtype=np.float32) / np.float32(255)
+    text = "WorldBegin\n" + "".join(f'Texture "t{i}" "spectrum" "imagemap" "string filename" "{n}"\n'
+                                    for i, n in enumerate(cases)) + "WorldEnd\n"
+    (tmp_path / "scene.pbrt").write_text(text)
+    ls = loader.load_pbrt(str(tmp_path / "scene.pbrt"))  # owns the tables d points into
+    d = ls.desc
+    assert d.n_images == len(cases)
+    for i, name in enumerate(cases):
+        assert (d.images[i].width, d.images[i].height) == (w, h)
+        got = np.frombuffer(C.string_at(d.images[i].rgba, h * w * 16), np.float32).reshape(h, w, 4)
+        v = expect[name]
+        lin = np.where(v <= 0.04045, v / 12.92, ((v + 0.055) / 1.055) ** 2.4)
+        np.testing.assert_allclose(got[..., :3], lin[..., :3], rtol=2e-6, atol=1e-7)
+        np.testing.assert_array_equal(got[..., 3], v[..., 3])
+    # 16-bit and interlaced files are refused, not mis-decoded; so are other LDR formats
+    Image.fromarray(rgba[..., 0].astype(np.uint16) << 8).save(tmp_path / "deep.png")  # uint16 -> 16-bit grey
+    for name, code in (("deep.png", -4), ("missing.png", -6), ("x.jpg", -4)):
+        (tmp_path / "bad.pbrt").write_text(f'WorldBegin\nTexture "t" "spectrum" "imagemap" "string filename" "{name}"\nWorldEnd\n')
+        with pytest.raises(api.ReneError) as e:
+            loader.load_pbrt(str(tmp_path / "bad.pbrt"))
+        assert e.value.code == code, (name, str(e.value))
+    (tmp_path / "trunc.png").write_bytes((tmp_path / "rgb.png").read_bytes()[:60])
+    (tmp_path / "bad.pbrt").write_text('WorldBegin\nTexture "t" "spectrum" "imagemap" "string filename" "trunc.png"\nWorldEnd\n')
+    with pytest.raises(api.ReneError) as e:
+        loader.load_pbrt(str(tmp_path / "bad.pbrt"))
+    assert e.value.code == -6 and "PNG decode error" in str(e.value)
+
+
 @pytest.mark.reference
 @pytest.mark.skipif(not have_reference(), reason="needs /root/reference/sample_scenes")
 def test_reference_sample_scenes(hip_lib):
