@@ -45,10 +45,10 @@ TARGET_SPP = 1024
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def pmc_traffic(frames_per_step: int, n_gpus: int):
-    """HBM bytes per render_kernel launch from the rocprofv3 --pmc passes committed under
-    profiles/ (FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE as is); None if absent or
-    collected for a different launch shape."""
+def pmc_record(frames_per_step: int, n_gpus: int):
+    """The rocprofv3 --pmc summary committed under profiles/ for this launch shape (None if absent or
+    collected for a different shape): HBM bytes per render_kernel launch (FETCH_SIZE doubled per the
+    gfx950 correction, WRITE_SIZE as is) and the SQ_* instruction counts of the same launch."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
         rec = json.load(open(path))
@@ -56,7 +56,26 @@ def pmc_traffic(frames_per_step: int, n_gpus: int):
         return None
     if rec.get("frames_per_step") != frames_per_step or rec.get("n_gpus", 1) != n_gpus:
         return None
-    return rec.get("hbm_bytes_per_launch")
+    return rec
+
+
+def pmc_traffic(frames_per_step: int, n_gpus: int):
+    rec = pmc_record(frames_per_step, n_gpus)
+    return rec.get("hbm_bytes_per_launch") if rec else None
+
+
+def valu_issue(frames_per_step: int, n_gpus: int, launch_ms: float, cus: int, clock_ghz: float):
+    """What actually bounds the kernel: the share of VALU issue cycles in use.  A wave64 VALU
+    instruction occupies its SIMD16 for 4 cycles; there are 4 SIMDs per CU.  Instruction count from the
+    committed PMC pass (SQ_INSTS_VALU per launch), duration measured live."""
+    rec = pmc_record(frames_per_step, n_gpus)
+    if not rec or not rec.get("valu_wave_insts_per_launch") or launch_ms <= 0:
+        return None
+    insts = rec["valu_wave_insts_per_launch"]
+    avail = cus * 4 * launch_ms * 1e-3 * clock_ghz * 1e9
+    return {"valu_wave_insts_per_launch": insts, "issue_cycles_frac": insts * 4.0 / avail,
+            "lane_ops_per_ray": None, "clock_ghz": clock_ghz, "cus": cus,
+            "source": f"profiles/{rec.get('tag', '')}_pmc.txt (SQ_INSTS_VALU) / live launch duration"}
 
 
 def main():
@@ -160,6 +179,10 @@ def main():
         launch_ms = st.kernel_ms / max(1, st.launches)
         alg_bytes_per_launch = bytes_per_ray * st.rays / max(1, st.launches)
         achieved = alg_bytes_per_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+        prop = torch.cuda.get_device_properties(local)
+        valu = valu_issue(F, n_gpus, launch_ms, prop.multi_processor_count, 2.4)  # 2.4 GHz: MI355X peak engine clock
+        if valu:
+            valu["lane_ops_per_ray"] = valu["valu_wave_insts_per_launch"] * 64.0 / max(1.0, st.rays / max(1, st.launches))
         out = {
             "metric": "Mrays/s", "value": total_rays / elapsed / 1e6, "unit": "Mrays/s",
             "n_gpus": n_gpus, "steps": K, "warmup": Wm, "ms_per_step": elapsed / K * 1e3,
@@ -177,6 +200,7 @@ def main():
                          "kernel": "render_kernel", "launch_ms": launch_ms,
                          "algorithmic_bytes_per_ray": bytes_per_ray,
                          "algorithmic_bytes_per_launch": alg_bytes_per_launch,
+                         "valu": valu,
                          "note": "cache-less model (SURVEY 8d); the 36-triangle scene is cache resident, "
                                  "so real HBM traffic (`traffic`) is far below it: the kernel is VALU/latency bound"},
         }

@@ -317,3 +317,34 @@ def dragon_class(xres: int = 1920, yres: int = 1080, n_lat: int = 640, n_lon: in
     s.add_triangle_mesh(displaced_sphere(n_lat, n_lon), clay, ctm=glam.from_translation((0.33, 0.48, 0.35)))
     s.add_light_distant((-0.18862, 0.692312, 0.69651), (0.0, 0.0, 0.0), (8.0, 8.0, 8.0))
     return s
+
+
+# ---------------------------------------------------------------------------------------------------
+# teapot-class (BASELINE config 5): sample_scenes/teapot/scene.pbrt is 126 048 triangles of Substrate
+# (Ks 0.04, roughness 0.001, remaproughness false) on a Matte floor with a 20 x 20 checkerboard under an
+# infinite light with an environment map; its env map is absent from the reference checkout
+# (.MISSING_LARGE_BLOBS) and its meshes may not be copied, so this is a stand-in of the same
+# character built in code: a displaced sphere of the same triangle count, same materials, same light kind.
+# ---------------------------------------------------------------------------------------------------
+def teapot_class(xres: int = 1920, yres: int = 1080, n_lat: int = 250, n_lon: int = 252) -> Scene:
+    s = Scene.new()
+    s.film.filename = "teapot-class.png"
+    s.set_camera(glam.look_at_lh((0.0, 1.6, -5.2), (0.0, 0.55, 0.0), (0.0, 1.0, 0.0)), 30.0, xres, yres)
+    hh, ww = 64, 128
+    v = np.linspace(0.0, 1.0, hh, dtype=F32)[:, None]
+    u = np.linspace(0.0, 1.0, ww, dtype=F32)[None, :]
+    sky = np.ones((hh, ww, 4), dtype=F32)
+    sky[..., 0] = 0.35 + 0.5 * v
+    sky[..., 1] = 0.45 + 0.4 * v
+    sky[..., 2] = 0.75 + 0.15 * v
+    sun = np.exp(-((u - 0.3) ** 2 + (v - 0.75) ** 2) / 0.002).astype(F32)
+    sky[..., :3] += 6.0 * sun[..., None]
+    s.set_infinite_light((1.0, 1.0, 1.0), image=sky)
+    t1, t2 = s.add_texture_solid((0.325, 0.31, 0.25)), s.add_texture_solid((0.725, 0.71, 0.68))
+    floor_mat = s.add_matte(s.add_texture_checkerboard(t1, t2, 20.0, 20.0))
+    body = s.add_substrate((0.9, 0.9, 0.9), (0.04, 0.04, 0.04), 0.001, 0.001, remap_roughness=False)
+    s.add_triangle_mesh(TriangleMesh.from_arrays([-8, 0, -8, 8, 0, -8, 8, 0, 8, -8, 0, 8], _QUAD_IDX,
+                                                 normals=[(0, 1, 0)] * 4, uvs=_QUAD_UV), floor_mat)
+    s.add_triangle_mesh(displaced_sphere(n_lat, n_lon, radius=0.8, amplitude=0.18, seed=11), body,
+                        ctm=glam.from_translation((0.0, 0.95, 0.0)))
+    return s

@@ -23,6 +23,16 @@ if only == "vol":
     run("cornell vacuum 1024x1024 (volpath)", s, 32)
     run("media-zoo 1024x768 (volpath)", scenes.media_zoo(1024, 768), 16)
     sys.exit(0)
+if only == "bvh":
+    for nm, sc, F in (("C4 dragon-class 1920x1080", scenes.dragon_class(1920, 1080), 16), ("C5 teapot-class 1920x1080", scenes.teapot_class(1920, 1080), 16)):
+        run(nm, sc, F)
+        with api.Renderer(sc, flags=abi.FLAG_COUNTERS) as rc:
+            rc.render(0, 2); c = rc.stats().as_dict()
+        print("   per ray:", {k: round(c[k] / c["rays"], 2) for k in ("node_visits", "prim_tests", "hits", "adds")}, "rays split", {k: round(c[k]/c["rays"], 3) for k in ("rays_closest", "rays_shadow", "rays_emitter")}, flush=True)
+        with api.Renderer(sc, flags=abi.FLAG_NO_RESTART) as r2:
+            r2.render(0, 4); r2.sync(); r2.reset(); r2.render(0, F); r2.sync(); st = r2.stats()
+        print(f"   while-while kernel: {st.rays/st.kernel_ms/1e3:.0f} Mrays/s", flush=True)
+    sys.exit(0)
 run("C2 cornell 1024x1024", scenes.cornell_box(1024, 1024), 64)
 run("C3 veach-mis 1024x1024", scenes.veach_mis(1024, 1024), 64)
 run("C3 veach-mis 1024x1024 (BVH)", scenes.veach_mis(1024, 1024), 64) if False else None

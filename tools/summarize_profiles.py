@@ -71,6 +71,12 @@ def main():
                "hbm_bytes_per_launch": rd + wr,
                "correction": "read = FETCH_SIZE KiB * 1024 * 2 (gfx950 counts 128-B requests at 64 B); write = WRITE_SIZE KiB * 1024",
                "command": cmd}
+        if "SQ_INSTS_VALU" in traffic:  # the compute side of the same launch shape, from the SQ_* pass
+            rec["valu_wave_insts_per_launch"] = traffic["SQ_INSTS_VALU"]
+            rec["salu_wave_insts_per_launch"] = traffic.get("SQ_INSTS_SALU")
+            rec["wave_cycles_per_launch"] = traffic.get("SQ_WAVE_CYCLES")
+            rec["wait_any_cycles_per_launch"] = traffic.get("SQ_WAIT_INST_ANY")
+            rec["waves_per_launch"] = traffic.get("SQ_WAVES")
         json.dump(rec, open(os.path.join(out, "hbm_traffic.json"), "w"), indent=1)
     print(open(os.path.join(out, f"{tag}_kernel_stats.txt")).read()[:1500])
     print(open(os.path.join(out, f"{tag}_pmc.txt")).read()[:3000])
