@@ -12,11 +12,31 @@ struct LaunchConfig {
   uint32_t stack_depth = 16; // LDS traversal stack entries per lane
   uint32_t grid = 0;         // workgroups of the persistent render launch (upper bound)
   uint32_t cus = 0;          // compute units of the device
+  uint32_t wave_stack = 0;   // wavefront integrator: LDS traversal stack entries per lane (exact tree depth)
 };
 
 hipError_t launch_render(const LaunchConfig& cfg, const SceneView& S, const RenderParams& P, hipStream_t st);
 hipError_t launch_render_bvh(const LaunchConfig& cfg, const SceneView& S, const RenderParams& P, hipStream_t st);
 hipError_t launch_render_vol(const LaunchConfig& cfg, const SceneView& S, const RenderParams& P, hipStream_t st);
+// stage-separated wavefront integrator (wavefront.inc, kernels_wave.hip): path state in HBM, SoA
+struct WaveState {
+  float4* ro;        // xyz ray origin
+  float4* rd;        // xyz ray direction
+  float4* color;     // rgb throughput; w = BSDF pdf awaiting the emitter-pdf ray
+  uint4* ctl;        // x rng state, y frame-wide rng state, z depth, w next frame of this slot
+  float4* hit;       // t, u, v, bits(slot)
+  float4* sh_wi;     // [max_lights][n_slots] shadow ray direction (xyz)
+  float4* sh_c;      // [max_lights][n_slots] contribution if unoccluded (rgb)
+  uint32_t* status;  // WS_* bits
+  uint32_t* n_done;  // slots that have finished all their frames
+  unsigned long long* wave_sums;  // [waves][8] per-wave counter rows (folded into the context's counters at the end)
+  uint32_t n_slots;
+  uint32_t max_lights;
+};
+hipError_t launch_wave_init(const WaveState& Q, hipStream_t st);
+hipError_t launch_wave_finish(const RenderParams& P, const WaveState& Q, hipStream_t st);
+hipError_t launch_wave_rounds(const LaunchConfig& cfg, const SceneView& S, const RenderParams& P, const WaveState& Q,
+                              uint32_t rounds, hipStream_t st);
 hipError_t launch_trace(const LaunchConfig& cfg, const SceneView& S, int which, uint32_t n, const float* o,
                         const float* d, float tmin, float tmax, rene_hit* out, hipStream_t st);
 hipError_t launch_bsdf_eval(const SceneView& S, uint32_t material, uint32_t n, const float* nrm3, const float* uv,

@@ -73,6 +73,10 @@ struct rene_ctx {
   uint32_t* d_item_done = nullptr;
   uint32_t epoch = 0;
   unsigned long long* d_counters = nullptr;
+  // stage-separated wavefront integrator (BVH scenes): path state in HBM + a pinned word for the host loop
+  bool wavefront = false;
+  rene::WaveState wave{};
+  uint32_t* h_done = nullptr;
   // per-launch resources that must outlive the asynchronous launch
   struct Pending {
     hipEvent_t start, stop;
@@ -289,6 +293,37 @@ int rene_create(const rene_scene_desc* scene, const rene_opts* opts, rene_ctx** 
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->fb), c->fb_floats * sizeof(float)));
     c->own_fb = true;
   }
+  // Which integrator renders this scene: the item-loop megakernel (small scenes), the volpath megakernel,
+  // or -- for everything that needs the BVH -- the stage-separated wavefront (wavefront.inc) unless the
+  // caller asks for one of the megakernels (A/B tests) or the scene has more distant lights than the
+  // wavefront keeps shadow-ray slots for.
+  constexpr uint32_t kWaveMaxLights = 4;
+  c->cfg.wave_stack = std::max(1u, depth);
+  c->wavefront = !(c->cfg.features & (rene::FEAT_SMALL | rene::FEAT_VOLPATH)) &&
+                 !(o.flags & (RENE_FLAG_NO_RESTART | RENE_FLAG_MEGAKERNEL)) && ps.lights.size() <= kWaveMaxLights &&
+                 c->n_work > 0;
+  if (c->wavefront) {
+    rene::WaveState& q = c->wave;
+    q.n_slots = c->n_work;
+    q.max_lights = (uint32_t)ps.lights.size();
+    const size_t n = q.n_slots;
+    auto dev = [&](void** p, size_t bytes) {
+      hipError_t e = hipMalloc(p, std::max<size_t>(16, bytes));
+      if (e == hipSuccess) c->allocations.push_back(*p);
+      return e;
+    };
+    HIP_TRY(dev(reinterpret_cast<void**>(&q.ro), n * 16));
+    HIP_TRY(dev(reinterpret_cast<void**>(&q.rd), n * 16));
+    HIP_TRY(dev(reinterpret_cast<void**>(&q.color), n * 16));
+    HIP_TRY(dev(reinterpret_cast<void**>(&q.ctl), n * 16));
+    HIP_TRY(dev(reinterpret_cast<void**>(&q.hit), n * 16));
+    HIP_TRY(dev(reinterpret_cast<void**>(&q.sh_wi), n * 16 * q.max_lights));
+    HIP_TRY(dev(reinterpret_cast<void**>(&q.sh_c), n * 16 * q.max_lights));
+    HIP_TRY(dev(reinterpret_cast<void**>(&q.status), n * 4));
+    HIP_TRY(dev(reinterpret_cast<void**>(&q.n_done), 4));
+    HIP_TRY(dev(reinterpret_cast<void**>(&q.wave_sums), ((n + 255) / 256) * 4 * 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_done), sizeof(uint32_t)));
+  }
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_work_counter), sizeof(uint32_t)));
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_counters), 16 * sizeof(unsigned long long)));
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_item_done), std::max<size_t>(1, c->n_work) * sizeof(uint32_t)));
@@ -316,6 +351,7 @@ void rene_destroy(rene_ctx* c) {
   if (c->d_work_counter) hipFree(c->d_work_counter);
   if (c->d_counters) hipFree(c->d_counters);
   if (c->d_item_done) hipFree(c->d_item_done);
+  if (c->h_done) hipHostFree(c->h_done);
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
   delete c;
 }
@@ -373,6 +409,37 @@ int rene_render(rene_ctx* c, uint32_t first_frame, uint32_t n_frames) {
   P.leaf_min = 16;
   if (const char* e = std::getenv("RENE_READY_MIN")) P.ready_min = (uint32_t)std::max(1, std::atoi(e));  // tuning knobs
   if (const char* e = std::getenv("RENE_LEAF_MIN")) P.leaf_min = (uint32_t)std::max(1, std::atoi(e));
+  if (c->wavefront) {
+    // Host-driven rounds of three kernels (wavefront.inc) until every slot has rendered its frames.  The
+    // number of rounds is the largest number of bounces any pixel needs over the launch's frames, known
+    // only to the device: run a batch sized from the frame count, then poll the done counter (a 4-byte
+    // copy + one stream sync per batch).  rene_render is therefore synchronous for these scenes.
+    rene::LaunchConfig cfg = c->cfg;
+    hipEventRecord(pend.start, c->stream);
+    e = rene::launch_wave_init(c->wave, c->stream);
+    uint32_t batch = std::max(8u, 2u * P.n_frames);
+    uint64_t rounds = 0;
+    const uint64_t max_rounds = 64ull + 51ull * P.n_frames;  // depth cap 50 (lib.rs:192) + regeneration rounds
+    while (e == hipSuccess) {
+      e = rene::launch_wave_rounds(cfg, c->view, P, c->wave, batch, c->stream);
+      rounds += batch;
+      if (e == hipSuccess) e = hipMemcpyAsync(c->h_done, c->wave.n_done, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+      if (e != hipSuccess || *c->h_done >= c->wave.n_slots) break;
+      if (rounds > max_rounds) {
+        hipEventRecord(pend.stop, c->stream);
+        c->pending.push_back(pend);
+        return fail(RENE_ERR_DEVICE, "wavefront integrator: pixels left unfinished after the maximum number of rounds");
+      }
+      batch = std::max(8u, P.n_frames / 4u);
+    }
+    if (e == hipSuccess) e = rene::launch_wave_finish(P, c->wave, c->stream);
+    hipEventRecord(pend.stop, c->stream);
+    c->pending.push_back(pend);
+    c->launches++;
+    if (e != hipSuccess) return fail(RENE_ERR_DEVICE, std::string("wavefront launch: ") + hipGetErrorString(e));
+    return c->drain();
+  }
   rene::LaunchConfig cfg = c->cfg;
   // launch no more lanes than there are work items; hand items out in batches small enough that every
   // launched wave gets some (a tile shard of a small image has fewer items than the chip has lanes)
