@@ -193,7 +193,7 @@ enum {
   RENE_FLAG_SINGLE_LEVEL = 1u << 3, /* one work item per pixel per launch (no long/short split; same results, for A/B tests) */
   RENE_FLAG_NO_RESTART = 1u << 4, /* BVH scenes: use the plain while-while kernel instead of the traversal-restart one (A/B tests) */
   RENE_FLAG_DYNAMIC_FIRST = 1u << 5, /* every work batch, the first included, comes from the atomic counter (A/B tests) */
-  RENE_FLAG_MEGAKERNEL = 1u << 6 /* BVH scenes: the traversal-restart megakernel instead of the stage-separated wavefront (A/B tests) */
+  RENE_FLAG_WAVEFRONT = 1u << 6 /* BVH scenes: the stage-separated wavefront integrator (wavefront.inc) instead of the traversal-restart megakernel */
 };
 enum { RENE_SHARD_TILES = 0, RENE_SHARD_FRAMES = 1 };
 

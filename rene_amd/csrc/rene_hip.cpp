@@ -294,13 +294,13 @@ int rene_create(const rene_scene_desc* scene, const rene_opts* opts, rene_ctx** 
     c->own_fb = true;
   }
   // Which integrator renders this scene: the item-loop megakernel (small scenes), the volpath megakernel,
-  // or -- for everything that needs the BVH -- the stage-separated wavefront (wavefront.inc) unless the
-  // caller asks for one of the megakernels (A/B tests) or the scene has more distant lights than the
-  // wavefront keeps shadow-ray slots for.
+  // or -- for everything that needs the BVH -- the traversal-restart megakernel; RENE_FLAG_WAVEFRONT selects
+  // the stage-separated wavefront (wavefront.inc) instead, unless the scene has more distant lights than
+  // it keeps shadow-ray slots for.
   constexpr uint32_t kWaveMaxLights = 4;
   c->cfg.wave_stack = std::max(1u, depth);
   c->wavefront = !(c->cfg.features & (rene::FEAT_SMALL | rene::FEAT_VOLPATH)) &&
-                 !(o.flags & (RENE_FLAG_NO_RESTART | RENE_FLAG_MEGAKERNEL)) && ps.lights.size() <= kWaveMaxLights &&
+                 (o.flags & RENE_FLAG_WAVEFRONT) && !(o.flags & RENE_FLAG_NO_RESTART) && ps.lights.size() <= kWaveMaxLights &&
                  c->n_work > 0;
   if (c->wavefront) {
     rene::WaveState& q = c->wave;

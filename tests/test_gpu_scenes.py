@@ -118,15 +118,15 @@ def test_teapot_class_substrate_checkerboard_envmap(oracle_mod):
 
 @pytest.mark.parametrize("name", ["dragon", "zoo", "teapot", "cornell"])
 def test_wavefront_equals_megakernels_bit_for_bit(name):
-    """The three schedulings of the BVH integrator -- stage-separated wavefront (default, wavefront.inc),
-    traversal-restart megakernel (RENE_FLAG_MEGAKERNEL) and while-while megakernel (RENE_FLAG_NO_RESTART) --
+    """The three schedulings of the BVH integrator -- stage-separated wavefront (RENE_FLAG_WAVEFRONT, wavefront.inc),
+    traversal-restart megakernel (default) and while-while megakernel (RENE_FLAG_NO_RESTART) --
     run the same arithmetic in the same order: identical images (all three layers) and identical counters,
     also across launch splits and tile shards."""
     s = {"dragon": lambda: scenes.dragon_class(96, 54, 24, 26), "zoo": lambda: scenes.material_zoo(64, 48),
          "teapot": lambda: scenes.teapot_class(96, 54, 20, 22), "cornell": lambda: scenes.cornell_box(48, 48)}[name]()
     force = abi.FLAG_FORCE_BVH
     imgs, stats = [], []
-    for flags in (0, abi.FLAG_MEGAKERNEL, abi.FLAG_NO_RESTART):
+    for flags in (abi.FLAG_WAVEFRONT, 0, abi.FLAG_NO_RESTART):
         with api.Renderer(s, flags=force | abi.FLAG_COUNTERS | flags) as r:
             r.render(0, 7)
             imgs.append([r.download(k) for k in range(3)])
@@ -142,14 +142,14 @@ def test_wavefront_equals_megakernels_bit_for_bit(name):
             # general-BSDF instantiations that costs an occasional last-bit difference (seen: 1 value in 9216)
             np.testing.assert_allclose(imgs[0][k], imgs[1][k], rtol=1e-6, atol=1e-7)
             assert (imgs[0][k] != imgs[1][k]).mean() < 1e-3
-    with api.Renderer(s, flags=force) as r:  # launch split
+    with api.Renderer(s, flags=force | abi.FLAG_WAVEFRONT) as r:  # launch split
         r.render(0, 3)
         r.render(3, 4)
         for k in range(3):
             np.testing.assert_array_equal(r.download(k), imgs[0][k])
     acc = np.zeros_like(imgs[0][0])
     for rank in range(3):  # tile shards
-        with api.Renderer(s, flags=force | abi.FLAG_NO_AOV, shard_mode=abi.SHARD_TILES, shard_rank=rank, shard_count=3) as r:
+        with api.Renderer(s, flags=force | abi.FLAG_NO_AOV | abi.FLAG_WAVEFRONT, shard_mode=abi.SHARD_TILES, shard_rank=rank, shard_count=3) as r:
             r.render(0, 7)
             acc += r.download(0)
     np.testing.assert_array_equal(acc, imgs[0][0])
