@@ -29,6 +29,7 @@ struct WaveState {
   float4* sh_c;      // [max_lights][n_slots] contribution if unoccluded (rgb)
   uint32_t* status;  // WS_* bits
   uint32_t* n_done;  // slots that have finished all their frames
+  uint32_t* trace_counter;  // [2] next ray id of the closest-hit / secondary traversal pass
   unsigned long long* wave_sums;  // [waves][8] per-wave counter rows (folded into the context's counters at the end)
   uint32_t n_slots;
   uint32_t max_lights;

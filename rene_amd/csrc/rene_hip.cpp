@@ -321,6 +321,7 @@ int rene_create(const rene_scene_desc* scene, const rene_opts* opts, rene_ctx** 
     HIP_TRY(dev(reinterpret_cast<void**>(&q.sh_c), n * 16 * q.max_lights));
     HIP_TRY(dev(reinterpret_cast<void**>(&q.status), n * 4));
     HIP_TRY(dev(reinterpret_cast<void**>(&q.n_done), 4));
+    HIP_TRY(dev(reinterpret_cast<void**>(&q.trace_counter), 8));
     HIP_TRY(dev(reinterpret_cast<void**>(&q.wave_sums), ((n + 255) / 256) * 4 * 8 * sizeof(unsigned long long)));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_done), sizeof(uint32_t)));
   }

@@ -32,6 +32,10 @@ if only == "bvh":
         with api.Renderer(sc, flags=abi.FLAG_NO_RESTART) as r2:
             r2.render(0, 4); r2.sync(); r2.reset(); r2.render(0, F); r2.sync(); st = r2.stats()
         print(f"   while-while kernel: {st.rays/st.kernel_ms/1e3:.0f} Mrays/s", flush=True)
+        for FF in (F, 64):
+            with api.Renderer(sc, flags=abi.FLAG_WAVEFRONT) as r2:
+                r2.render(0, 4); r2.sync(); r2.reset(); r2.render(0, FF); r2.sync(); st = r2.stats()
+            print(f"   wavefront ({FF} frames/launch): {st.rays/st.kernel_ms/1e3:.0f} Mrays/s, {st.kernel_ms/st.frames:.3f} ms/frame", flush=True)
     sys.exit(0)
 run("C2 cornell 1024x1024", scenes.cornell_box(1024, 1024), 64)
 run("C3 veach-mis 1024x1024", scenes.veach_mis(1024, 1024), 64)
