@@ -11,7 +11,10 @@ static hipError_t launch_bvh(const LaunchConfig& cfg, const SceneView& S, const 
   bool count = (P0.flags & RENE_FLAG_COUNTERS) != 0, aov = !(P0.flags & RENE_FLAG_NO_AOV);
   RenderParams P = P0;
   auto kernel = render_kernel_wf<FEAT, MAXL, false, false>;
-  if (P.flags & RENE_FLAG_NO_RESTART) kernel = (count || aov) ? render_kernel<FEAT, MAXL, true, true> : render_kernel<FEAT, MAXL, false, false>;
+  // a tree of a few hundred nodes is shallow and its rays stay coherent: the plain while-while loop wins there
+  // (forced-BVH Cornell 17.2 vs 10.9, veach-mis 10.8 vs 6.3, zoo 5.1 vs 3.3 Grays/s); deep trees need the restart
+  // scheduling (teapot-class 4.4 vs 3.5, dragon-class 4.4 vs 2.0)
+  if ((P.flags & RENE_FLAG_NO_RESTART) || S.main.n_nodes <= 512u) kernel = (count || aov) ? render_kernel<FEAT, MAXL, true, true> : render_kernel<FEAT, MAXL, false, false>;
   else if (count) kernel = render_kernel_wf<FEAT, MAXL, true, true>;
   else if (aov) kernel = render_kernel_wf<FEAT, MAXL, false, true>;
   fit_grid(kernel, lds, cfg, P, grid);

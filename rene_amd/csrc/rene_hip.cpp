@@ -261,7 +261,7 @@ int rene_create(const rene_scene_desc* scene, const rene_opts* opts, rene_ctx** 
   // traversal stack: enough for the deeper of the two trees, in LDS, [depth][256 lanes]
   uint32_t depth = std::max(ps.main.depth, ps.emit.depth);
   uint32_t stack = 16;
-  while (stack < depth) stack += 16;
+  while (stack < depth) stack += 4;  // 40 entries x 1024 lanes x 4 B = the whole 160 KB of a CU at 4 waves per SIMD
   if (stack > 96) return fail(RENE_ERR_UNSUPPORTED, "BVH deeper than the 96-entry traversal stack");
   c->cfg.features = ps.features;
   if (o.flags & RENE_FLAG_FORCE_BVH) c->cfg.features &= ~rene::FEAT_SMALL;

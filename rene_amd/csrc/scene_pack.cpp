@@ -266,6 +266,120 @@ inline uint32_t float_bits(float f) {
   return u;
 }
 
+// ---- BVH2 -> BVH4 with 8-bit child boxes (device_scene.h, Node) ------------------------------------------
+// Collapse: a node adopts the children of its inner children -- shallowest first (both BVH2 children before any
+// grandchild, which halves the tree depth and with it the traversal stack), largest surface area among
+// equals -- until it has four children or only leaves.  Quantisation: child box corners on a 256-step grid anchored at the node's
+// origin with a power-of-two step per axis; lo rounded down, hi rounded up, so a decoded box always
+// contains the exact one.  Returns the worst-case traversal stack depth in `stack_need`.
+struct Collapse4 {
+  const std::vector<Node>& n2;
+  std::vector<Node> out;
+  struct Child { Box box; uint32_t word; int level = 1; };
+
+  explicit Collapse4(const std::vector<Node>& nodes) : n2(nodes) {}
+  static bool empty(const Box& b) { return !(b.lo[0] <= b.hi[0] && b.lo[1] <= b.hi[1] && b.lo[2] <= b.hi[2]); }
+  void children_of(uint32_t idx, std::vector<Child>& v) const {
+    const float* q = n2[idx].q;
+    Child a{{{q[0], q[1], q[2]}, {q[3], q[4], q[5]}}, float_bits(q[12]), 1};
+    Child b{{{q[6], q[7], q[8]}, {q[9], q[10], q[11]}}, float_bits(q[13]), 1};
+    if (!empty(a.box)) v.push_back(a);
+    if (!empty(b.box)) v.push_back(b);
+  }
+  static void encode(Node& n, const std::vector<Child>& ch) {
+    std::memset(&n, 0, sizeof(n));
+    uint32_t words[4] = {LEAF_BIT, LEAF_BIT, LEAF_BIT, LEAF_BIT};
+    uint8_t qlo[3][4], qhi[3][4];
+    for (int a = 0; a < 3; ++a)
+      for (int c = 0; c < 4; ++c) { qlo[a][c] = 255; qhi[a][c] = 0; }  // lo > hi: never hit
+    uint32_t ebytes = 0;
+    float origin[3] = {0, 0, 0};
+    if (!ch.empty()) {
+      for (int a = 0; a < 3; ++a) {
+        double lo = ch[0].box.lo[a], hi = ch[0].box.hi[a];
+        for (const Child& c : ch) { lo = std::min<double>(lo, c.box.lo[a]); hi = std::max<double>(hi, c.box.hi[a]); }
+        origin[a] = (float)lo;  // a child lo, exactly representable
+        double ext = hi - lo;
+        int e = -126;
+        if (ext > 0.0) {
+          int ex;
+          std::frexp(ext / 255.0, &ex);  // ext / 255 = m * 2^ex, m in [0.5, 1)  ->  2^ex >= ext / 255
+          e = std::max(-126, std::min(127, ex));
+        }
+        const double step = std::ldexp(1.0, e);
+        ebytes |= (uint32_t)(e + 127) << (8 * a);
+        for (size_t c = 0; c < ch.size(); ++c) {
+          double l = std::floor((ch[c].box.lo[a] - lo) / step), h = std::ceil((ch[c].box.hi[a] - lo) / step);
+          qlo[a][c] = (uint8_t)std::max(0.0, std::min(255.0, l));
+          qhi[a][c] = (uint8_t)std::max(0.0, std::min(255.0, h));
+        }
+      }
+      for (size_t c = 0; c < ch.size(); ++c) words[c] = ch[c].word;
+    }
+    n.q[0] = origin[0]; n.q[1] = origin[1]; n.q[2] = origin[2];
+    n.q[3] = bits_to_float(ebytes);
+    for (int c = 0; c < 4; ++c) n.q[4 + c] = bits_to_float(words[c]);
+    for (int a = 0; a < 3; ++a) {
+      n.q[8 + a] = bits_to_float(qlo[a][0] | (qlo[a][1] << 8) | (qlo[a][2] << 16) | ((uint32_t)qlo[a][3] << 24));
+      n.q[11 + a] = bits_to_float(qhi[a][0] | (qhi[a][1] << 8) | (qhi[a][2] << 16) | ((uint32_t)qhi[a][3] << 24));
+    }
+  }
+  uint32_t run() {  // returns the stack entries a traversal can need
+    out.clear();
+    out.emplace_back();
+    struct Item { uint32_t src, dst; };
+    std::vector<Item> work{{0u, 0u}};
+    std::vector<std::vector<uint32_t>> kids(1);
+    std::vector<uint32_t> nchild(1, 0);
+    while (!work.empty()) {
+      Item it = work.back();
+      work.pop_back();
+      std::vector<Child> ch;
+      children_of(it.src, ch);
+      for (;;) {
+        if (ch.size() >= 4) break;
+        int pick = -1;
+        float best = -1.0f;
+        int level = 1 << 30;
+        for (size_t c = 0; c < ch.size(); ++c)
+          if (!(ch[c].word & LEAF_BIT) &&
+              (ch[c].level < level || (ch[c].level == level && ch[c].box.half_area() > best))) {
+            level = ch[c].level;
+            best = ch[c].box.half_area();
+            pick = (int)c;
+          }
+        if (pick < 0) break;
+        std::vector<Child> sub;
+        children_of(ch[pick].word, sub);
+        for (Child& s : sub) s.level = ch[pick].level + 1;
+        if (ch.size() - 1 + sub.size() > 4) break;
+        ch.erase(ch.begin() + pick);
+        ch.insert(ch.end(), sub.begin(), sub.end());
+      }
+      for (Child& c : ch)
+        if (!(c.word & LEAF_BIT)) {
+          uint32_t idx = (uint32_t)out.size();
+          out.emplace_back();
+          kids.emplace_back();
+          nchild.push_back(0);
+          work.push_back({c.word, idx});
+          kids[it.dst].push_back(idx);
+          c.word = idx;
+        }
+      nchild[it.dst] = (uint32_t)ch.size();
+      encode(out[it.dst], ch);
+    }
+    // children are always created after their parent: one reverse sweep computes the stack bound
+    std::vector<uint32_t> need(out.size(), 0);
+    for (size_t i = out.size(); i-- > 0;) {
+      uint32_t m = 0;
+      for (uint32_t k : kids[i]) m = std::max(m, need[k]);
+      need[i] = (nchild[i] ? nchild[i] - 1 : 0) + m;
+    }
+    return need[0] + 1;
+  }
+};
+
 // Small-scene item list over the slots of a built structure: merge triangle pairs of one instance
 // that share an edge X-Y and whose third vertices satisfy Z1 + Z2 = X + Y (a parallelogram).
 void build_small_items(BuiltAccel& acc) {
@@ -360,8 +474,9 @@ void finish_accel(const std::vector<Prim>& prims, uint32_t max_leaf, BuiltAccel&
                   std::vector<uint32_t>& order) {
   Builder b(prims, max_leaf);
   b.build();
-  out.nodes = std::move(b.nodes);
-  out.depth = b.max_depth + 1;
+  Collapse4 wide(b.nodes);
+  out.depth = wide.run();
+  out.nodes = std::move(wide.out);
   out.isect.resize(prims.size());
   for (size_t s = 0; s < prims.size(); ++s) out.isect[s] = prims[b.order[s]].isect;
   order = std::move(b.order);
