@@ -21,7 +21,7 @@ identical to one GPU, but a rank's launches shrink with N).  value = rays of all
 The JSON line also carries
   roofline     -- dominant kernel (render_kernel): algorithmic bytes per launch (SURVEY.md 8d cache-less
                   model, evaluated from the node/primitive counters of an untimed counting pass over
-                  this build's BVH2) / average launch duration from HIP events recorded on the
+                  this build's BVH4) / average launch duration from HIP events recorded on the
                   kernel's stream inside librene_hip.so, against the 8 TB/s HBM3E peak; `traffic` =
                   PMC-measured HBM bytes per launch when profiles/ holds them for this config;
   cpu_baseline -- the CPU oracle (a port of rene's integrator; the reference itself has no CPU
@@ -131,7 +131,7 @@ def main():
                 rdist.reduce_framebuffer(fb, dst=0)
 
     # ---- untimed: algorithmic bytes per ray from the kernel's own counters (same scene, seeds) ----
-    # (counted over this build's BVH2 -- RENE_FLAG_FORCE_BVH -- so that the figure does not depend on
+    # (counted over this build's BVH4 -- RENE_FLAG_FORCE_BVH -- so that the figure does not depend on
     # which intersection back end renders the scene: the small-scene item loop tests every item)
     cf = min(F, 8)
     with api.Renderer(packed, device=local, flags=abi.FLAG_COUNTERS | abi.FLAG_FORCE_BVH, shard_mode=abi.SHARD_TILES,

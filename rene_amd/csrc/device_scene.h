@@ -5,7 +5,7 @@
 // software traversal with 16-byte vector loads:
 //   * instancing is flattened: every triangle is stored once per instance in WORLD space
 //     (288 GB of HBM makes duplication cheap; one-level traversal has no ray re-transform);
-//   * a BVH2 node is one 64-byte record (both child boxes + both links) = one cache line;
+//   * a BVH4 node is one 64-byte record (four 8-bit quantised child boxes + four links) = one cache line;
 //   * a primitive's intersection record is 48 bytes (3 x float4), its shading record 64 bytes,
 //     both stored in BVH leaf order so a leaf's primitives are contiguous.
 #pragma once
