@@ -107,6 +107,7 @@ class Renderer:
         o = abi.Opts()
         o.struct_size = C.sizeof(abi.Opts)
         o.seed, o.device, o.flags = seed & 0xFFFFFFFF, device, flags
+        self._flags = flags
         o.shard_mode, o.shard_rank, o.shard_count = shard_mode, shard_rank, shard_count
         o.framebuffer = framebuffer_ptr
         o.stream = stream_ptr

@@ -223,8 +223,8 @@ int rene_create(const rene_scene_desc* scene, const rene_opts* opts, rene_ctx** 
   UP(ps.emit.isect, v.emit.isect);
   UP(ps.main.items, v.main.items);
   UP(ps.emit.items, v.emit.items);
-  v.main.n_items = (uint32_t)ps.main.items.size();
-  v.emit.n_items = (uint32_t)ps.emit.items.size();
+  v.main.n_items = ps.main.n_loop;  // the loop's items; the auxiliary records of box items follow them
+  v.emit.n_items = ps.emit.n_loop;
   v.main.n_nodes = (uint32_t)ps.main.nodes.size();
   v.main.n_slots = (uint32_t)ps.main.isect.size();
   v.emit.n_nodes = (uint32_t)ps.emit.nodes.size();

@@ -416,10 +416,13 @@ void build_small_items(BuiltAccel& acc) {
     it.q[10] = (float)-(ux * ox + uy * oy + uz * oz);
     it.q[11] = (float)-(vx * ox + vy * oy + vz * oz);
   };
+  struct Geo { V3 O, a, b; uint32_t inst; bool quad; };
+  std::vector<Geo> geo;  // the surface of every item, for the parallelepiped merge below
   auto emit_tri = [&](size_t s) {
     SmallItem it;
     std::memset(&it, 0, sizeof(it));
     const float* q = acc.isect[s].q;
+    geo.push_back(Geo{V3{q[0], q[1], q[2]}, V3{q[3], q[4], q[5]}, V3{q[6], q[7], q[8]}, t[s].inst, false});
     if (!t[s].sphere) surface(it, V3{q[0], q[1], q[2]}, V3{q[3], q[4], q[5]}, V3{q[6], q[7], q[8]});  // O = p0, a = e1, b = e2
     it.q[12] = t[s].sphere ? SMALL_KIND_SPHERE : SMALL_KIND_TRIANGLE;
     it.q[13] = bits_to_float((uint32_t)s);
@@ -455,6 +458,7 @@ void build_small_items(BuiltAccel& acc) {
       SmallItem it;
       std::memset(&it, 0, sizeof(it));
       surface(it, Z1, sub(X, Z1), sub(Y, Z1));
+      geo.push_back(Geo{Z1, sub(X, Z1), sub(Y, Z1), t[i].inst, true});
       it.q[12] = SMALL_KIND_QUAD;
       it.q[13] = bits_to_float((uint32_t)i);
       it.q[14] = bits_to_float((uint32_t)j);
@@ -468,7 +472,137 @@ void build_small_items(BuiltAccel& acc) {
     }
     if (!merged) emit_tri(i);
   }
-  if (acc.items.size() > SMALL_MAX_ITEMS) acc.items.clear();
+  // ---- six parallelograms of one instance that bound a parallelepiped become ONE box item: three slab pairs in
+  // the box's own (skew) coordinates instead of six plane tests (Cornell: two boxes, 18 items -> 8; veach-mis:
+  // four plates, 29 -> 9).  A line meets a convex box in its entry and exit faces, which are exactly the
+  // parallelograms the six separate tests would report.
+  {
+    auto add = [](V3 p, V3 q) { return V3{p.x + q.x, p.y + q.y, p.z + q.z}; };
+    auto corner = [&](V3 O, V3 a, V3 b, V3 c, int i, int j, int k) {
+      V3 p = O;
+      if (i) p = add(p, a);
+      if (j) p = add(p, b);
+      if (k) p = add(p, c);
+      return p;
+    };
+    std::vector<SmallItem> items;
+    std::vector<SmallItem> aux;
+    std::vector<char> gone(acc.items.size(), 0);
+    struct Box6 { size_t first; SmallItem item; SmallItem aux; };
+    std::vector<Box6> boxes;
+    for (size_t i0 = 0; i0 < acc.items.size(); ++i0) {
+      if (gone[i0] || !geo[i0].quad) continue;
+      std::vector<size_t> g;
+      for (size_t j = 0; j < acc.items.size(); ++j)
+        if (!gone[j] && geo[j].inst == geo[i0].inst) g.push_back(j);
+      bool all_quads = g.size() == 6;
+      for (size_t j : g) all_quads = all_quads && geo[j].quad;
+      if (!all_quads) continue;
+      float scale = 0.f;
+      for (size_t j : g)
+        for (V3 p : {geo[j].O, add(geo[j].O, geo[j].a), add(geo[j].O, geo[j].b)})
+          scale = std::max(scale, std::max(std::fabs(p.x), std::max(std::fabs(p.y), std::fabs(p.z))));
+      const float tol = 8e-6f * std::max(scale, 1e-3f);
+      const Geo& q0 = geo[g[0]];
+      // the third edge: a corner of another face that completes O + {0,1}a + {0,1}b + {0,1}c
+      bool made = false;
+      for (size_t j : g) {
+        if (made || j == g[0]) continue;
+        for (int cj = 0; cj < 4 && !made; ++cj) {
+          V3 p = corner(geo[j].O, geo[j].a, geo[j].b, V3{0, 0, 0}, cj & 1, cj >> 1, 0);
+          V3 c = sub(p, q0.O);
+          // every face must be one of the six faces of (O, a, b, c); remember which, and how its (s, r) run
+          struct Face { int item = -1; uint32_t map = 0; } face[6];
+          bool ok = true;
+          for (size_t f : g) {
+            // corner coordinates (i, j, k) of the face's O, O + a, O + b in the candidate box
+            int cc[3][3];
+            V3 pts[3] = {geo[f].O, add(geo[f].O, geo[f].a), add(geo[f].O, geo[f].b)};
+            bool found_all = true;
+            for (int v = 0; v < 3 && found_all; ++v) {
+              bool found = false;
+              for (int m = 0; m < 8 && !found; ++m)
+                if (close(pts[v], corner(q0.O, q0.a, q0.b, c, m & 1, (m >> 1) & 1, m >> 2), tol)) {
+                  cc[v][0] = m & 1; cc[v][1] = (m >> 1) & 1; cc[v][2] = m >> 2;
+                  found = true;
+                }
+              found_all = found;
+            }
+            if (!found_all) { ok = false; break; }
+            // the face's axis: the coordinate all three corners share; its s / r run along the other two
+            int axis = -1, s_ax = -1, r_ax = -1;
+            for (int ax = 0; ax < 3; ++ax) {
+              if (cc[0][ax] == cc[1][ax] && cc[0][ax] == cc[2][ax]) axis = ax;
+              if (cc[0][ax] != cc[1][ax]) s_ax = ax;
+              if (cc[0][ax] != cc[2][ax]) r_ax = ax;
+            }
+            if (axis < 0 || s_ax < 0 || r_ax < 0 || s_ax == r_ax || s_ax == axis || r_ax == axis) { ok = false; break; }
+            int fi = axis * 2 + cc[0][axis];
+            if (face[fi].item >= 0) { ok = false; break; }
+            face[fi].item = (int)f;
+            // in-face coordinates are the two box coordinates != axis in ascending order: index 0 or 1
+            auto in_face = [&](int ax) { return ax > axis ? ax - 1 : ax; };
+            face[fi].map = (uint32_t)in_face(s_ax) | ((uint32_t)(cc[0][s_ax] ? 1 : 0) << 2) |
+                           ((uint32_t)in_face(r_ax) << 3) | ((uint32_t)(cc[0][r_ax] ? 1 : 0) << 5);
+          }
+          for (int fi = 0; fi < 6 && ok; ++fi) ok = face[fi].item >= 0;
+          if (!ok) continue;
+          // reciprocal basis of (a, b, c): a' = (b x c) / det, b' = (c x a) / det, c' = (a x b) / det
+          const double A[3] = {q0.a.x, q0.a.y, q0.a.z}, B[3] = {q0.b.x, q0.b.y, q0.b.z}, Cc[3] = {c.x, c.y, c.z};
+          auto crossd = [](const double* u, const double* v, double* o) {
+            o[0] = u[1] * v[2] - u[2] * v[1]; o[1] = u[2] * v[0] - u[0] * v[2]; o[2] = u[0] * v[1] - u[1] * v[0];
+          };
+          double bc[3], ca[3], ab[3];
+          crossd(B, Cc, bc); crossd(Cc, A, ca); crossd(A, B, ab);
+          const double det = A[0] * bc[0] + A[1] * bc[1] + A[2] * bc[2];
+          if (!(std::fabs(det) > 0.0) || !std::isfinite(det)) continue;
+          Box6 bx;
+          bx.first = g[0];
+          std::memset(&bx.item, 0, sizeof(SmallItem));
+          std::memset(&bx.aux, 0, sizeof(SmallItem));
+          const double* rec[3] = {bc, ca, ab};
+          for (int ax = 0; ax < 3; ++ax) {
+            double r0 = rec[ax][0] / det, r1 = rec[ax][1] / det, r2 = rec[ax][2] / det;
+            bx.item.q[4 * ax + 0] = (float)r0; bx.item.q[4 * ax + 1] = (float)r1; bx.item.q[4 * ax + 2] = (float)r2;
+            bx.item.q[4 * ax + 3] = (float)-(r0 * q0.O.x + r1 * q0.O.y + r2 * q0.O.z);
+          }
+          bx.item.q[12] = SMALL_KIND_BOX;
+          for (int fi = 0; fi < 6; ++fi) {
+            const SmallItem& src = acc.items[face[fi].item];
+            uint32_t s1 = float_bits(src.q[13]), s2 = float_bits(src.q[14]), perm = float_bits(src.q[15]);
+            bx.aux.q[2 * fi] = bits_to_float((s1 & 0xffu) | ((s2 & 0xffu) << 8) | ((perm & 0xffffu) << 16));
+            bx.aux.q[2 * fi + 1] = bits_to_float(face[fi].map);
+          }
+          for (size_t f : g) gone[f] = 1;
+          boxes.push_back(bx);
+          made = true;
+        }
+      }
+    }
+    if (!boxes.empty()) {
+      for (size_t i = 0; i < acc.items.size(); ++i) {
+        for (const Box6& bx : boxes)
+          if (bx.first == i) items.push_back(bx.item);
+        if (!gone[i]) items.push_back(acc.items[i]);
+      }
+      // aux records follow the loop items; a box item names its aux record by absolute index
+      size_t nb = 0;
+      const size_t n_loop = items.size();
+      for (SmallItem& it : items)
+        if (it.q[12] == SMALL_KIND_BOX) it.q[13] = bits_to_float((uint32_t)(n_loop + nb++));
+      for (const Box6& bx : boxes) aux.push_back(bx.aux);
+      // (boxes were pushed in the order of their first item, which is the order the loop above re-emits them)
+      std::sort(boxes.begin(), boxes.end(), [](const Box6& x, const Box6& y) { return x.first < y.first; });
+      aux.clear();
+      for (const Box6& bx : boxes) aux.push_back(bx.aux);
+      items.insert(items.end(), aux.begin(), aux.end());
+      acc.items = std::move(items);
+      acc.n_loop = (uint32_t)n_loop;
+    } else {
+      acc.n_loop = (uint32_t)acc.items.size();
+    }
+  }
+  if (acc.n_loop > SMALL_MAX_ITEMS || acc.isect.size() > 255) { acc.items.clear(); acc.n_loop = 0; }
 }
 
 void finish_accel(const std::vector<Prim>& prims, uint32_t max_leaf, BuiltAccel& out,

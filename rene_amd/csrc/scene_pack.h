@@ -13,7 +13,9 @@ namespace rene {
 struct BuiltAccel {
   std::vector<Node> nodes;
   std::vector<PrimIsect> isect;  // slot order
-  std::vector<SmallItem> items;  // small-scene item list (empty if the structure is too large)
+  std::vector<SmallItem> items;  // small-scene item list (empty if the structure is too large): n_loop items the
+                                 // wave-coherent loop visits, then one auxiliary record per box item
+  uint32_t n_loop = 0;
   uint32_t depth = 0;            // max stack depth a traversal can need
 };
 

@@ -130,6 +130,10 @@ def cornell_fog(xres: int = 1024, yres: int = 1024) -> Scene:
     s.instances[inst].material_index = 0  # None: a pure medium boundary
     s.instances[inst].interior_medium_index = cloud
     s.instances[inst].exterior_medium_index = fog
+    # lifted 1 cm off the floor: the Cornell box's short box stands ON the floor (bottom face within 3e-8 of it),
+    # and with a None material the order in which two coincident surfaces are met decides which medium the floor
+    # is in -- a coin flip of rounding that no two intersection formulas resolve alike
+    s.instances[inst].matrix[:] = glam.affine_from_mat4(glam.from_translation((0.0, 0.01, 0.0)))
     s.add_triangle_mesh(_aabb((-0.995, 0.005, -0.995), (0.995, 1.9, 0.995)), 0, interior=fog, exterior=0)
     return s
 

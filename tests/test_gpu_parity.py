@@ -70,7 +70,11 @@ def test_traversal_matches_oracle(cornell128, which):
     assert disagree.sum() <= 2, disagree.sum()  # an edge-grazing ray may flip; none expected
     both = ~miss_g & ~miss_o & (hg["primitive"] == ho["primitive"])
     assert both.sum() > 100
-    np.testing.assert_allclose(hg["t"][both], ho["t"][both], rtol=2e-5, atol=1e-6)
+    # BVH path: the oracle's Moeller-Trumbore arithmetic, a few ulp.  Item loop: planes and box slabs evaluate the ray
+    # parameter from world-space dot products (n.O - n.o, O.x' - o.x'), which cancels for origins close to the surface:
+    # an absolute error of ~1e-5 scene units at Cornell's scale, 1 % of tmin
+    atol = 2e-5 if (api.pack_info(cornell128[0]).features & 64) and not (cornell128[2]._flags & abi.FLAG_FORCE_BVH) else 1e-6
+    np.testing.assert_allclose(hg["t"][both], ho["t"][both], rtol=2e-5, atol=atol)
     np.testing.assert_allclose(hg["u"][both], ho["u"][both], atol=2e-5)
     np.testing.assert_allclose(hg["v"][both], ho["v"][both], atol=2e-5)
 
