@@ -100,6 +100,11 @@ def scene_to_pbrt(scene) -> str:
     for inst in scene.instances:
         lines = []
         scoped = bool(inst.area_light_index)
+        m = [float(v) for v in inst.matrix]  # Affine3A: x_axis, y_axis, z_axis, translation
+        if m != [1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0]:
+            cols = m[0:3] + [0.0] + m[3:6] + [0.0] + m[6:9] + [0.0] + m[9:12] + [1.0]
+            lines.append("ConcatTransform [ " + " ".join(repr(v) for v in cols) + " ]")
+            scoped = True
         if inst.interior_medium_index or inst.exterior_medium_index:
             lines.append(f'MediumInterface "{med(inst.interior_medium_index)}" "{med(inst.exterior_medium_index)}"')
             scoped = True
