@@ -142,7 +142,8 @@ constexpr float SMALL_KIND_QUAD = 0.0f, SMALL_KIND_TRIANGLE = 1.0f, SMALL_KIND_S
 // A box item (six parallelograms of one instance bounding a parallelepiped O + s a + r b + k c, s, r, k in [0, 1]):
 //   q[0..3], q[4..7], q[8..11] = a' -O.a' | b' -O.b' | c' -O.c'   (reciprocal basis: a'.a = 1, a'.b = a'.c = 0, ...):
 //   the coordinate of a point p along a is p.a' - O.a', in [0, 1] inside the box
-//   q[12] = SMALL_KIND_BOX, q[13] = bits(index of its auxiliary record in the same array)
+//   q[12] = SMALL_KIND_BOX, q[13] = bits(index of its auxiliary record in the same array), q[14] = bits(open face:
+//   0 none, 1 the face at coordinate 0 of the third axis, 2 the one at coordinate 1 -- a five-sided box)
 // auxiliary record, two words per face f = 2 * axis + side (side 0: coordinate 0, side 1: coordinate 1):
 //   q[2f]   = bits(slot1 | slot2 << 8 | perms << 16)          the two triangles of the face, as in a parallelogram item
 //   q[2f+1] = bits(sel_s | flip_s << 2 | sel_r << 3 | flip_r << 5)   the face's own (s, r) from the two in-face box

@@ -472,83 +472,101 @@ void build_small_items(BuiltAccel& acc) {
     }
     if (!merged) emit_tri(i);
   }
-  // ---- six parallelograms of one instance that bound a parallelepiped become ONE box item: three slab pairs in
-  // the box's own (skew) coordinates instead of six plane tests (Cornell: two boxes, 18 items -> 8; veach-mis:
-  // four plates, 29 -> 9).  A line meets a convex box in its entry and exit faces, which are exactly the
-  // parallelograms the six separate tests would report.
+  // ---- parallelograms that are faces of one parallelepiped become ONE box item: three slab pairs in the box's own
+  // (skew) coordinates instead of one plane test per face.  All six faces (Cornell's two blocks, veach-mis's four
+  // plates), or five with the sixth open (Cornell's room: floor, ceiling, back and side walls -- five instances).
+  // A line meets a convex box in its entry and exit faces, which are exactly the parallelograms the separate tests
+  // would report; an open face reports nothing.  Cornell: 18 items -> 4; veach-mis: 29 -> 9.
   {
     auto add = [](V3 p, V3 q) { return V3{p.x + q.x, p.y + q.y, p.z + q.z}; };
-    auto corner = [&](V3 O, V3 a, V3 b, V3 c, int i, int j, int k) {
+    auto corner = [&](V3 O, V3 a, V3 b, V3 c, int m) {
       V3 p = O;
-      if (i) p = add(p, a);
-      if (j) p = add(p, b);
-      if (k) p = add(p, c);
+      if (m & 1) p = add(p, a);
+      if (m & 2) p = add(p, b);
+      if (m & 4) p = add(p, c);
       return p;
     };
-    std::vector<SmallItem> items;
-    std::vector<SmallItem> aux;
-    std::vector<char> gone(acc.items.size(), 0);
-    struct Box6 { size_t first; SmallItem item; SmallItem aux; };
-    std::vector<Box6> boxes;
-    for (size_t i0 = 0; i0 < acc.items.size(); ++i0) {
-      if (gone[i0] || !geo[i0].quad) continue;
-      std::vector<size_t> g;
-      for (size_t j = 0; j < acc.items.size(); ++j)
-        if (!gone[j] && geo[j].inst == geo[i0].inst) g.push_back(j);
-      bool all_quads = g.size() == 6;
-      for (size_t j : g) all_quads = all_quads && geo[j].quad;
-      if (!all_quads) continue;
-      float scale = 0.f;
-      for (size_t j : g)
+    const size_t n_items = acc.items.size();
+    float scale = 0.f;
+    for (size_t j = 0; j < n_items; ++j)
+      if (geo[j].quad)
         for (V3 p : {geo[j].O, add(geo[j].O, geo[j].a), add(geo[j].O, geo[j].b)})
           scale = std::max(scale, std::max(std::fabs(p.x), std::max(std::fabs(p.y), std::fabs(p.z))));
-      const float tol = 8e-6f * std::max(scale, 1e-3f);
-      const Geo& q0 = geo[g[0]];
-      // the third edge: a corner of another face that completes O + {0,1}a + {0,1}b + {0,1}c
+    const float tol = 8e-6f * std::max(scale, 1e-3f);
+    struct Face { int item = -1; uint32_t map = 0; };
+    // which free parallelograms are faces of the box (O, e[0], e[1], e[2]); returns how many of the six were found
+    std::vector<char> gone(n_items, 0);
+    auto faces_of = [&](V3 O, const V3* e, Face* face) {
+      int found_faces = 0;
+      for (int fi = 0; fi < 6; ++fi) face[fi] = Face();
+      for (size_t f = 0; f < n_items; ++f) {
+        if (gone[f] || !geo[f].quad) continue;
+        int cc[3][3];
+        V3 pts[3] = {geo[f].O, add(geo[f].O, geo[f].a), add(geo[f].O, geo[f].b)};
+        bool all = true;
+        for (int v = 0; v < 3 && all; ++v) {
+          bool found = false;
+          for (int m = 0; m < 8 && !found; ++m)
+            if (close(pts[v], corner(O, e[0], e[1], e[2], m), tol)) {
+              cc[v][0] = m & 1; cc[v][1] = (m >> 1) & 1; cc[v][2] = m >> 2;
+              found = true;
+            }
+          all = found;
+        }
+        if (!all) continue;
+        // the face's axis: the coordinate all three corners share; its s / r run along the other two
+        int axis = -1, s_ax = -1, r_ax = -1;
+        for (int ax = 0; ax < 3; ++ax) {
+          if (cc[0][ax] == cc[1][ax] && cc[0][ax] == cc[2][ax]) axis = ax;
+          if (cc[0][ax] != cc[1][ax]) s_ax = ax;
+          if (cc[0][ax] != cc[2][ax]) r_ax = ax;
+        }
+        if (axis < 0 || s_ax < 0 || r_ax < 0 || s_ax == r_ax || s_ax == axis || r_ax == axis) continue;
+        int fi = axis * 2 + cc[0][axis];
+        if (face[fi].item >= 0) continue;  // a duplicate face stays a separate item
+        face[fi].item = (int)f;
+        // in-face coordinates are the two box coordinates != axis in ascending order: index 0 or 1
+        auto in_face = [&](int ax) { return ax > axis ? ax - 1 : ax; };
+        face[fi].map = (uint32_t)in_face(s_ax) | ((uint32_t)(cc[0][s_ax] ? 1 : 0) << 2) |
+                       ((uint32_t)in_face(r_ax) << 3) | ((uint32_t)(cc[0][r_ax] ? 1 : 0) << 5);
+        found_faces++;
+      }
+      return found_faces;
+    };
+    struct Box6 { size_t first; SmallItem item; SmallItem aux; };
+    std::vector<Box6> boxes;
+    for (size_t i0 = 0; i0 < n_items; ++i0) {
+      if (gone[i0] || !geo[i0].quad) continue;
+      const Geo& q0 = geo[i0];
       bool made = false;
-      for (size_t j : g) {
-        if (made || j == g[0]) continue;
+      // the third edge: a corner of another parallelogram, so that both are faces of O + {0,1}a + {0,1}b + {0,1}c
+      for (size_t j = 0; j < n_items && !made; ++j) {
+        if (j == i0 || gone[j] || !geo[j].quad) continue;
         for (int cj = 0; cj < 4 && !made; ++cj) {
-          V3 p = corner(geo[j].O, geo[j].a, geo[j].b, V3{0, 0, 0}, cj & 1, cj >> 1, 0);
-          V3 c = sub(p, q0.O);
-          // every face must be one of the six faces of (O, a, b, c); remember which, and how its (s, r) run
-          struct Face { int item = -1; uint32_t map = 0; } face[6];
-          bool ok = true;
-          for (size_t f : g) {
-            // corner coordinates (i, j, k) of the face's O, O + a, O + b in the candidate box
-            int cc[3][3];
-            V3 pts[3] = {geo[f].O, add(geo[f].O, geo[f].a), add(geo[f].O, geo[f].b)};
-            bool found_all = true;
-            for (int v = 0; v < 3 && found_all; ++v) {
-              bool found = false;
-              for (int m = 0; m < 8 && !found; ++m)
-                if (close(pts[v], corner(q0.O, q0.a, q0.b, c, m & 1, (m >> 1) & 1, m >> 2), tol)) {
-                  cc[v][0] = m & 1; cc[v][1] = (m >> 1) & 1; cc[v][2] = m >> 2;
-                  found = true;
-                }
-              found_all = found;
+          V3 e[3] = {q0.a, q0.b, sub(corner(geo[j].O, geo[j].a, geo[j].b, V3{0, 0, 0}, cj), q0.O)};
+          Face face[6];
+          int nf = faces_of(q0.O, e, face);
+          if (nf < 5) continue;
+          V3 O = q0.O;
+          uint32_t open_flag = 0;
+          if (nf == 5) {  // put the open face on the third axis, the one whose two parameters the loop still holds
+            int miss = 0;
+            for (int fi = 0; fi < 6; ++fi)
+              if (face[fi].item < 0) miss = fi;
+            const int m_ax = miss >> 1;
+            if (m_ax != 2) {
+              V3 t = e[m_ax];
+              e[m_ax] = e[2];
+              e[2] = t;
+              if (faces_of(O, e, face) != 5) continue;
+              for (int fi = 0; fi < 6; ++fi)
+                if (face[fi].item < 0) miss = fi;
             }
-            if (!found_all) { ok = false; break; }
-            // the face's axis: the coordinate all three corners share; its s / r run along the other two
-            int axis = -1, s_ax = -1, r_ax = -1;
-            for (int ax = 0; ax < 3; ++ax) {
-              if (cc[0][ax] == cc[1][ax] && cc[0][ax] == cc[2][ax]) axis = ax;
-              if (cc[0][ax] != cc[1][ax]) s_ax = ax;
-              if (cc[0][ax] != cc[2][ax]) r_ax = ax;
-            }
-            if (axis < 0 || s_ax < 0 || r_ax < 0 || s_ax == r_ax || s_ax == axis || r_ax == axis) { ok = false; break; }
-            int fi = axis * 2 + cc[0][axis];
-            if (face[fi].item >= 0) { ok = false; break; }
-            face[fi].item = (int)f;
-            // in-face coordinates are the two box coordinates != axis in ascending order: index 0 or 1
-            auto in_face = [&](int ax) { return ax > axis ? ax - 1 : ax; };
-            face[fi].map = (uint32_t)in_face(s_ax) | ((uint32_t)(cc[0][s_ax] ? 1 : 0) << 2) |
-                           ((uint32_t)in_face(r_ax) << 3) | ((uint32_t)(cc[0][r_ax] ? 1 : 0) << 5);
+            if ((miss >> 1) != 2) continue;
+            open_flag = 1u + (uint32_t)(miss & 1);
           }
-          for (int fi = 0; fi < 6 && ok; ++fi) ok = face[fi].item >= 0;
-          if (!ok) continue;
           // reciprocal basis of (a, b, c): a' = (b x c) / det, b' = (c x a) / det, c' = (a x b) / det
-          const double A[3] = {q0.a.x, q0.a.y, q0.a.z}, B[3] = {q0.b.x, q0.b.y, q0.b.z}, Cc[3] = {c.x, c.y, c.z};
+          const double A[3] = {e[0].x, e[0].y, e[0].z}, B[3] = {e[1].x, e[1].y, e[1].z}, Cc[3] = {e[2].x, e[2].y, e[2].z};
           auto crossd = [](const double* u, const double* v, double* o) {
             o[0] = u[1] * v[2] - u[2] * v[1]; o[1] = u[2] * v[0] - u[0] * v[2]; o[2] = u[0] * v[1] - u[1] * v[0];
           };
@@ -557,45 +575,44 @@ void build_small_items(BuiltAccel& acc) {
           const double det = A[0] * bc[0] + A[1] * bc[1] + A[2] * bc[2];
           if (!(std::fabs(det) > 0.0) || !std::isfinite(det)) continue;
           Box6 bx;
-          bx.first = g[0];
+          bx.first = i0;
           std::memset(&bx.item, 0, sizeof(SmallItem));
           std::memset(&bx.aux, 0, sizeof(SmallItem));
           const double* rec[3] = {bc, ca, ab};
           for (int ax = 0; ax < 3; ++ax) {
             double r0 = rec[ax][0] / det, r1 = rec[ax][1] / det, r2 = rec[ax][2] / det;
             bx.item.q[4 * ax + 0] = (float)r0; bx.item.q[4 * ax + 1] = (float)r1; bx.item.q[4 * ax + 2] = (float)r2;
-            bx.item.q[4 * ax + 3] = (float)-(r0 * q0.O.x + r1 * q0.O.y + r2 * q0.O.z);
+            bx.item.q[4 * ax + 3] = (float)-(r0 * O.x + r1 * O.y + r2 * O.z);
           }
           bx.item.q[12] = SMALL_KIND_BOX;
+          bx.item.q[14] = bits_to_float(open_flag);
           for (int fi = 0; fi < 6; ++fi) {
+            if (face[fi].item < 0) continue;
             const SmallItem& src = acc.items[face[fi].item];
             uint32_t s1 = float_bits(src.q[13]), s2 = float_bits(src.q[14]), perm = float_bits(src.q[15]);
             bx.aux.q[2 * fi] = bits_to_float((s1 & 0xffu) | ((s2 & 0xffu) << 8) | ((perm & 0xffffu) << 16));
             bx.aux.q[2 * fi + 1] = bits_to_float(face[fi].map);
+            gone[face[fi].item] = 1;
           }
-          for (size_t f : g) gone[f] = 1;
           boxes.push_back(bx);
           made = true;
         }
       }
     }
     if (!boxes.empty()) {
-      for (size_t i = 0; i < acc.items.size(); ++i) {
+      std::vector<SmallItem> items;
+      std::sort(boxes.begin(), boxes.end(), [](const Box6& x, const Box6& y) { return x.first < y.first; });
+      for (size_t i = 0; i < n_items; ++i) {
         for (const Box6& bx : boxes)
           if (bx.first == i) items.push_back(bx.item);
         if (!gone[i]) items.push_back(acc.items[i]);
       }
-      // aux records follow the loop items; a box item names its aux record by absolute index
-      size_t nb = 0;
+      // aux records follow the loop items, in the order of their boxes; a box item names its own by absolute index
       const size_t n_loop = items.size();
+      size_t nb = 0;
       for (SmallItem& it : items)
         if (it.q[12] == SMALL_KIND_BOX) it.q[13] = bits_to_float((uint32_t)(n_loop + nb++));
-      for (const Box6& bx : boxes) aux.push_back(bx.aux);
-      // (boxes were pushed in the order of their first item, which is the order the loop above re-emits them)
-      std::sort(boxes.begin(), boxes.end(), [](const Box6& x, const Box6& y) { return x.first < y.first; });
-      aux.clear();
-      for (const Box6& bx : boxes) aux.push_back(bx.aux);
-      items.insert(items.end(), aux.begin(), aux.end());
+      for (const Box6& bx : boxes) items.push_back(bx.aux);
       acc.items = std::move(items);
       acc.n_loop = (uint32_t)n_loop;
     } else {
