@@ -53,6 +53,7 @@ __global__ void __launch_bounds__(64) bsdf_eval_kernel(SceneView S, uint32_t mat
   f3 normal = normalize(mk3(nrm3[3 * i], nrm3[3 * i + 1], nrm3[3 * i + 2]));
   Bsdf<5> b;
   b.len = 0;
+  b.codes = 0xffffffffu;
   b.ng = normal;
   b.onb = onb_from_w(normal);
   compute_bsdf<ALL, 5>(S, inst, uv2{uv2_[2 * i], uv2_[2 * i + 1]}, b);
