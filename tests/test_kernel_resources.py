@@ -1,0 +1,58 @@
+"""CPU: register / scratch / spill figures of every gfx950 kernel, as the compiler reports them at build time
+(`-Rpass-analysis=kernel-resource-usage`, written to rene_amd/csrc/<unit>.res by the Makefile).
+
+The rule enforced here comes from a miscompile met on this toolchain: a kernel that spills
+SGPRs into VGPR lanes AND spills VGPRs to scratch returned garbage in long-lived per-lane values.  No shipped
+kernel may combine the two; the production variants of the hot kernels must also keep the occupancy their
+tuning assumes."""
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+CSRC = os.path.join(ROOT, "rene_amd", "csrc")
+UNITS = ("kernels", "kernels_bvh", "kernels_vol", "kernels_wave")
+
+
+def _kernels():
+    out = {}
+    for u in UNITS:
+        path = os.path.join(CSRC, u + ".res")
+        if not os.path.exists(path):
+            pytest.skip(f"{path} missing: build with `make -C rene_amd/csrc` (the Makefile writes it)")
+        text = open(path).read()
+        for m in re.finditer(r"Function Name: (\S+)(.*?)LDS Size", text, re.S):
+            g = lambda key: int(re.search(re.escape(key) + r": (\d+)", m.group(2)).group(1))
+            out[(u, m.group(1))] = {"sgpr": g("TotalSGPRs"), "vgpr": g("VGPRs"), "scratch": g("ScratchSize [bytes/lane]"),
+                                    "occupancy": g("Occupancy [waves/SIMD]"), "sgpr_spill": g("SGPRs Spill"),
+                                    "vgpr_spill": g("VGPRs Spill")}
+    return out
+
+
+def test_no_kernel_combines_sgpr_and_vgpr_spills(hip_lib):
+    ks = _kernels()
+    assert len(ks) >= 50
+    bad = {k[1]: v for k, v in ks.items() if v["sgpr_spill"] > 0 and v["vgpr_spill"] > 0}
+    assert not bad, bad
+
+
+def test_production_variants_keep_their_occupancy(hip_lib):
+    ks = {k[1]: v for k, v in _kernels().items()}
+    def one(substr):
+        hits = [v for n, v in ks.items() if substr in n]
+        assert len(hits) == 1, (substr, len(hits))
+        return hits[0]
+    # (first-hit layers on, counters off) variants: FEAT 72 = Matte small-scene kernel (the bench kernel), 95 = general
+    # single-lobe small-scene kernel, 8 / 31 = Matte / general traversal-restart kernels
+    assert one("render_kernelILj72ELi1ELb0ELb1")["occupancy"] >= 5 and one("render_kernelILj72ELi1ELb0ELb1")["scratch"] == 0
+    assert one("render_kernelILj95ELi1ELb0ELb1")["occupancy"] >= 3 and one("render_kernelILj95ELi1ELb0ELb1")["scratch"] == 0
+    assert one("render_kernel_wfILj8ELi1ELb0ELb1")["occupancy"] >= 4
+    assert one("render_kernel_wfILj31ELi1ELb0ELb1")["occupancy"] >= 3 and one("render_kernel_wfILj31ELi1ELb0ELb1")["scratch"] == 0
+    # multi-lobe kernels: two waves (they were at one, with 376 bytes of scratch per lane)
+    assert one("render_kernelILj127ELi5ELb0ELb1")["occupancy"] >= 2
+    # traversal passes of the wavefront integrator are register-light by construction
+    for n, v in ks.items():
+        if "wave_trace" in n:
+            assert v["vgpr"] <= 72 and v["occupancy"] >= 7 and v["scratch"] == 0, (n, v)
