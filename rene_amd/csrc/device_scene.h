@@ -221,6 +221,7 @@ struct RenderParams {
   uint32_t* item_done;     // [n_work] per-pixel hand-off flags
   uint32_t ready_min;      // traversal-restart kernel: lanes waiting before the logic step runs
   uint32_t leaf_min;       // traversal-restart kernel: lanes at a leaf before the leaf step runs
+  uint32_t split_div;      // the short item of a pixel covers the last n_frames / split_div frames (4)
   uint32_t static_waves;   // waves whose first batch is assigned statically (<= co-resident waves)
   uint32_t work_batch;     // work ids a wave takes per global atomic: 128 when items are plentiful, fewer
                            // (down to 16) when a launch has too few items to give every wave a full batch

@@ -400,6 +400,9 @@ int rene_render(rene_ctx* c, uint32_t first_frame, uint32_t n_frames) {
   P.n_tiles = c->n_tiles;
   P.flags = c->opts.flags;
   P.two_level = (P.n_frames >= 4 && !(c->opts.flags & RENE_FLAG_SINGLE_LEVEL)) ? 1u : 0u;
+  P.split_div = 4;
+  if (const char* e = std::getenv("RENE_SPLIT_DIV")) P.split_div = (uint32_t)std::max(2, std::min(64, std::atoi(e)));  // tuning knob
+  if (P.n_frames / P.split_div == 0) P.split_div = P.n_frames;  // the short item needs at least one frame
   if (++c->epoch == 0) {  // the flag array never needs clearing between launches unless the epoch wraps
     hipMemsetAsync(c->d_item_done, 0, std::max<size_t>(1, c->n_work) * sizeof(uint32_t), c->stream);
     c->epoch = 1;
