@@ -138,7 +138,8 @@ struct SmallItem {
   float q[16];
 };
 constexpr uint32_t SMALL_MAX_ITEMS = 64;
-constexpr float SMALL_KIND_QUAD = 0.0f, SMALL_KIND_TRIANGLE = 1.0f, SMALL_KIND_SPHERE = 2.0f, SMALL_KIND_BOX = 3.0f;
+constexpr float SMALL_KIND_QUAD = 0.0f, SMALL_KIND_TRIANGLE = 1.0f, SMALL_KIND_SPHERE = 2.0f, SMALL_KIND_BOX = 3.0f,
+                SMALL_KIND_BALL = 4.0f;  // a sphere whose transform is translation + uniform scale: q[0..2] = centre, q[3] = radius^2
 // A box item (six parallelograms of one instance bounding a parallelepiped O + s a + r b + k c, s, r, k in [0, 1]):
 //   q[0..3], q[4..7], q[8..11] = a' -O.a' | b' -O.b' | c' -O.c'   (reciprocal basis: a'.a = 1, a'.b = a'.c = 0, ...):
 //   the coordinate of a point p along a is p.a' - O.a', in [0, 1] inside the box

@@ -425,6 +425,10 @@ void build_small_items(BuiltAccel& acc) {
     geo.push_back(Geo{V3{q[0], q[1], q[2]}, V3{q[3], q[4], q[5]}, V3{q[6], q[7], q[8]}, t[s].inst, false});
     if (!t[s].sphere) surface(it, V3{q[0], q[1], q[2]}, V3{q[3], q[4], q[5]}, V3{q[6], q[7], q[8]});  // O = p0, a = e1, b = e2
     it.q[12] = t[s].sphere ? SMALL_KIND_SPHERE : SMALL_KIND_TRIANGLE;
+    if (t[s].sphere && q[4] == 1.0f) {  // centre, radius^2 (pack_scene)
+      it.q[0] = q[0]; it.q[1] = q[1]; it.q[2] = q[2]; it.q[3] = q[3];
+      it.q[12] = SMALL_KIND_BALL;
+    }
     it.q[13] = bits_to_float((uint32_t)s);
     it.q[14] = bits_to_float((uint32_t)s);
     it.q[15] = bits_to_float((1u | (2u << 2)) * 0x101u);  // u = weight of O+a, v = weight of O+b
@@ -797,6 +801,19 @@ int pack_scene(const rene_scene_desc* d, PackedScene& out, std::string& err) {
       p.isect.q[9] = bits_to_float(ii);
       p.isect.q[10] = bits_to_float(0u);
       p.isect.q[11] = bits_to_float(sidx);
+      {  // a translated, uniformly scaled unit sphere (every sphere the pbrt loader makes): centre and radius^2 for
+         // the item loop's short form of sphere_intersection; q[4] = 1 marks it
+        const float* m = in.matrix;
+        const float r = m[0];
+        const float tolr = 1e-6f * std::fabs(r);
+        if (r > 0.0f && std::fabs(m[4] - r) <= tolr && std::fabs(m[8] - r) <= tolr && std::fabs(m[1]) <= tolr &&
+            std::fabs(m[2]) <= tolr && std::fabs(m[3]) <= tolr && std::fabs(m[5]) <= tolr && std::fabs(m[6]) <= tolr &&
+            std::fabs(m[7]) <= tolr) {
+          p.isect.q[0] = m[9]; p.isect.q[1] = m[10]; p.isect.q[2] = m[11];
+          p.isect.q[3] = r * r;
+          p.isect.q[4] = 1.0f;
+        }
+      }
       prims.push_back(p);
       if (emitter) {
         eprims.push_back(p);
