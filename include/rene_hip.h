@@ -248,6 +248,8 @@ typedef struct rene_pack_info {
   uint32_t emit_object_len;  /* rene/src/main.rs:3279 */
   uint32_t lights_len;       /* rene/src/scene.rs:166 */
   uint64_t device_bytes;     /* HBM the scene tables will occupy (framebuffer excluded) */
+  uint32_t n_items_main;     /* items the small-scene loop visits per ray (0: the scene uses the BVH), main / emitter-only */
+  uint32_t n_items_emit;
 } rene_pack_info;
 
 typedef struct rene_ctx rene_ctx;

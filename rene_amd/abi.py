@@ -120,7 +120,7 @@ class PackInfo(C.Structure):
                 ("n_nodes_main", u32), ("n_slots_main", u32), ("depth_main", u32),
                 ("n_nodes_emit", u32), ("n_slots_emit", u32), ("depth_emit", u32),
                 ("features", u32), ("emit_object_len", u32), ("lights_len", u32),
-                ("device_bytes", u64)]
+                ("device_bytes", u64), ("n_items_main", u32), ("n_items_emit", u32)]
 
     def as_dict(self) -> dict:
         return {name: getattr(self, name) for name, _ in self._fields_}

@@ -148,6 +148,8 @@ int rene_scene_pack_info(const rene_scene_desc* scene, rene_pack_info* out) {
   out->features = ps.features;
   out->emit_object_len = (uint32_t)ps.emit_objects.size();
   out->lights_len = (uint32_t)ps.lights.size();
+  out->n_items_main = (ps.features & rene::FEAT_SMALL) ? ps.main.n_loop : 0u;
+  out->n_items_emit = (ps.features & rene::FEAT_SMALL) ? ps.emit.n_loop : 0u;
   out->device_bytes = ps.main.nodes.size() * sizeof(rene::Node) + ps.main.isect.size() * sizeof(rene::PrimIsect) +
                       ps.emit.nodes.size() * sizeof(rene::Node) + ps.emit.isect.size() * sizeof(rene::PrimIsect) +
                       ps.shade.size() * sizeof(rene::PrimShade) + ps.emit_pdf.size() * sizeof(rene::EmitPdf) +

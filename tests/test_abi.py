@@ -92,6 +92,11 @@ def test_pack_info_cornell(hip_lib):
     assert info["n_triangles"] == 36 and info["n_instances"] == 8 and info["n_spheres"] == 0
     assert info["emit_object_len"] == 1 and info["lights_len"] == 0 and info["n_slots_emit"] == 2
     assert info["features"] == 64  # Matte-only fast path + FEAT_SMALL (wave-coherent item loop)
+    # 36 triangles -> 18 parallelograms -> the room (five-sided box) + two blocks + the light; the emitter structure: the light
+    assert info["n_items_main"] == 4 and info["n_items_emit"] == 1
+    v = api.pack_info(scenes.veach_mis(64, 64)).as_dict()
+    assert v["n_items_main"] == 9  # 4 plates (boxes) + 2 walls + 3 spheres
+    assert api.pack_info(scenes.dragon_class(64, 36, 24, 26)).n_items_main == 0  # BVH scene
     assert info["n_slots_main"] == 36 and 1 <= info["n_nodes_main"] < 36
 
 

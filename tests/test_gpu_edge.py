@@ -92,3 +92,77 @@ def test_axis_parallel_and_grazing_rays(oracle_mod):
     assert bad.sum() <= 0.01 * n, bad.sum()  # coplanar starts are ties by construction
     ok = ~mg & ~mo & (hg["primitive"] == ho["primitive"])
     np.testing.assert_allclose(hg["t"][ok], ho["t"][ok], rtol=5e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_box_item_merging_on_random_parallelepipeds(oracle_mod, seed):
+    """The item loop merges parallelograms into box items (five or six faces of a parallelepiped, any instances).  Random
+    scenes of rotated, sheared and mirrored boxes -- closed, with one face missing, sharing a face, built from one mesh or
+    from one mesh per face -- plus loose quads and a sphere: every closest hit (instance, primitive, t, u, v) must equal
+    the oracle's, which knows nothing about items."""
+    rng = np.random.default_rng(seed)
+    s = Scene.new()
+    _camera(s, 16, 16)
+    s.set_infinite_light((1.0, 1.0, 1.0))
+    mats = [s.add_matte(tuple(rng.uniform(0.2, 0.9, 3))) for _ in range(3)]
+
+    def rand_affine(scale):
+        a = rng.normal(size=(3, 3))
+        qm, _ = np.linalg.qr(a)
+        shear = np.eye(3) + np.triu(rng.uniform(-0.4, 0.4, (3, 3)), 1)
+        m3 = qm @ shear @ np.diag(rng.uniform(0.4, 1.0, 3) * scale * rng.choice([-1.0, 1.0], 3))
+        m = np.eye(4, dtype=np.float32)
+        m[:3, :3] = m3
+        m[:3, 3] = rng.uniform(-1.5, 1.5, 3)
+        return m.T.copy() if False else m
+
+    def box_faces(lo, hi):
+        mesh = scenes._aabb(lo, hi)
+        v, idx = mesh.vertices, mesh.indices
+        return [TriangleMesh.from_arrays(v[:, 0:3].reshape(-1), idx[6 * f: 6 * f + 6], normals=v[:, 3:6], uvs=v[:, 6:8].reshape(-1))
+                for f in range(6)]
+
+    n_boxes = int(rng.integers(2, 5))
+    for b in range(n_boxes):
+        ctm = glam.from_cols_array(rand_affine(0.5).T.reshape(-1).tolist())
+        style = int(rng.integers(0, 4))
+        faces = box_faces((-1, -1, -1), (1, 1, 1))
+        if style == 0:  # one mesh, six faces
+            s.add_triangle_mesh(scenes._aabb((-1, -1, -1), (1, 1, 1)), mats[b % 3], ctm=ctm)
+        elif style == 1:  # one instance per face (different materials), all six
+            for f in range(6):
+                s.add_triangle_mesh(faces[f], mats[f % 3], ctm=ctm)
+        elif style == 2:  # five faces: one side open
+            skip = int(rng.integers(0, 6))
+            for f in range(6):
+                if f != skip:
+                    s.add_triangle_mesh(faces[f], mats[f % 3], ctm=ctm)
+        else:  # two boxes sharing a face (the shared face appears twice)
+            s.add_triangle_mesh(scenes._aabb((-1, -1, -1), (0, 1, 1)), mats[0], ctm=ctm)
+            s.add_triangle_mesh(scenes._aabb((0, -1, -1), (1, 1, 1)), mats[1], ctm=ctm)
+    for _ in range(int(rng.integers(0, 3))):  # loose quads
+        ctm = glam.from_cols_array(rand_affine(0.7).T.reshape(-1).tolist())
+        s.add_triangle_mesh(TriangleMesh.from_arrays([-1, 0, -1, 1, 0, -1, 1, 0, 1, -1, 0, 1], [0, 1, 2, 0, 2, 3]), mats[0], ctm=ctm)
+    s.add_sphere(0.4, mats[1], ctm=glam.from_translation(tuple(rng.uniform(-1, 1, 3))))
+    info = api.pack_info(s)
+    if not (info.features & 64):
+        pytest.skip("scene too large for the item loop")
+    n_quads = (info.n_triangles) // 2
+    assert info.n_items_main < n_quads + 1  # at least one box was formed (a sphere adds one item)
+    o = oracle_mod.Oracle(s)
+    n = 60000
+    org = rng.uniform(-2.5, 2.5, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    with api.Renderer(s) as r:
+        hg = r.trace(org, d)
+    ho = o.trace(org, d)
+    mg, mo = hg["t"] < 0, ho["t"] < 0
+    tie = np.abs(hg["t"] - ho["t"]) <= 2e-5 * (1 + np.abs(ho["t"]))  # coincident faces of adjacent boxes, edges
+    wrong = (mg != mo) | (~mo & ~mg & ~tie)
+    assert wrong.sum() <= 3, (int(wrong.sum()), int((mg != mo).sum()))
+    same = ~mg & ~mo & (hg["instance"] == ho["instance"]) & (hg["primitive"] == ho["primitive"])
+    assert same.sum() > 0.9 * (~mo).sum()  # the rest are ties between coincident / adjacent faces
+    np.testing.assert_allclose(hg["t"][same], ho["t"][same], rtol=5e-5, atol=5e-5)
+    np.testing.assert_allclose(hg["u"][same], ho["u"][same], atol=2e-4)
+    np.testing.assert_allclose(hg["v"][same], ho["v"][same], atol=2e-4)
