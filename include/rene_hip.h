@@ -281,7 +281,7 @@ int rene_framebuffer(rene_ctx* ctx, void** device_ptr, size_t* n_floats);
 int rene_get_stats(rene_ctx* ctx, rene_stats* out);
 
 /* Batch closest-hit queries against the main (which == 0) or emitter-only (which == 1) structure;
- * host pointers.  Exposes the traversal the Vulkan driver hides. */
+ * host pointers; 0 <= tmin <= tmax.  Exposes the traversal the Vulkan driver hides. */
 int rene_trace(rene_ctx* ctx, int which, size_t n, const float* origins, const float* directions,
                float tmin, float tmax, rene_hit* out);
 

@@ -548,6 +548,8 @@ int rene_trace(rene_ctx* c, int which, size_t n, const float* origins, const flo
                float tmax, rene_hit* out) {
   if (!c || (n && (!origins || !directions || !out))) return fail(RENE_ERR_INVALID_ARGUMENT, "rene_trace: NULL argument");
   if (which != 0 && which != 1) return fail(RENE_ERR_INVALID_ARGUMENT, "which must be 0 (main) or 1 (emitters)");
+  // the traversal orders children by the bit pattern of their (non-negative) entry distance
+  if (!(tmin >= 0.0f) || !(tmax >= tmin)) return fail(RENE_ERR_INVALID_ARGUMENT, "rene_trace: need 0 <= tmin <= tmax");
   if (n == 0) return RENE_OK;
   if (n > 0x7fffffffull) return fail(RENE_ERR_INVALID_ARGUMENT, "too many rays in one batch");
   HIP_TRY(hipSetDevice(c->device));

@@ -187,6 +187,14 @@ def test_create_errors_on_gpu():
     with pytest.raises(api.ReneError) as e:
         api.Renderer(s, shard_rank=3, shard_count=2)
     assert e.value.code == -1
+    with api.Renderer(s) as r:  # rene_trace: 0 <= tmin <= tmax
+        o = np.zeros((4, 3), np.float32)
+        d = np.tile(np.float32([0, 0, 1]), (4, 1))
+        for tmin, tmax in ((-1.0, 10.0), (2.0, 1.0), (float("nan"), 1.0)):
+            with pytest.raises(api.ReneError) as e:
+                r.trace(o, d, tmin=tmin, tmax=tmax)
+            assert e.value.code == -1
+        assert (r.trace(o, d, tmin=0.0, tmax=1e5)["t"] != 0).all()
 
 
 @pytest.mark.parametrize("res,frames", [((1024, 1024), 64), ((160, 96), 7), ((96, 64), 4), ((64, 64), 3), ((200, 120), 33)])
