@@ -169,3 +169,35 @@ def test_render_path_fails_loudly_without_gpu(hip_lib):
     with pytest.raises(api.ReneError) as e:
         api.Renderer(scenes.cornell_box(16, 16))
     assert e.value.code == -3  # RENE_ERR_DEVICE: no CPU fallback
+
+
+def test_item_merging_counts_on_the_host(hip_lib):
+    """build_small_items (scene_pack.cpp) without a GPU: triangles -> parallelograms -> box items."""
+    def info(build):
+        s = _tiny()
+        build(s)
+        return api.pack_info(s)
+    m = lambda s: s.add_matte((0.5, 0.5, 0.5))
+    rot = glam.mul(glam.from_translation((0.3, -0.2, 2.0)), glam.mul(glam.from_axis_angle((0.3, 0.8, 0.5), 0.7), glam.from_scale((0.5, 0.9, -0.7))))
+    box = scenes._aabb((-1, -1, -1), (1, 1, 1))
+    # a closed box of one mesh, rotated, scaled and mirrored: 12 triangles -> 1 item
+    assert info(lambda s: s.add_triangle_mesh(box, m(s), ctm=rot)).n_items_main == 1
+    # the same box as six instances, one per face
+    v, idx = box.vertices, box.indices
+    faces = [TriangleMesh.from_arrays(v[:, 0:3].reshape(-1), idx[6 * f: 6 * f + 6], normals=v[:, 3:6], uvs=v[:, 6:8].reshape(-1)) for f in range(6)]
+    def six(s, skip=()):
+        for f in range(6):
+            if f not in skip:
+                s.add_triangle_mesh(faces[f], m(s), ctm=rot)
+    assert info(six).n_items_main == 1
+    assert info(lambda s: six(s, skip=(2,))).n_items_main == 1      # five faces: an open box
+    assert info(lambda s: six(s, skip=(2, 3))).n_items_main == 4    # four faces: four parallelograms
+    # two triangles that do not form a parallelogram stay two items; a lone triangle is one
+    tri2 = TriangleMesh.from_arrays([0, 0, 3, 1, 0, 3, 0, 1, 3, 1.5, 1.2, 3], [0, 1, 2, 1, 3, 2])
+    assert info(lambda s: s.add_triangle_mesh(tri2, m(s))).n_items_main == 2
+    # more than 64 items: the scene leaves the item loop
+    def many(s):
+        for k in range(70):
+            s.add_triangle_mesh(TriangleMesh.from_arrays([k, 0, 3, k + 0.5, 0, 3, k, 1, 3], [0, 1, 2]), m(s))
+    i = info(many)
+    assert i.n_items_main == 0 and not (i.features & 64)
