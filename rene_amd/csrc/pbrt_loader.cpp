@@ -12,7 +12,7 @@
 // integrators select volpath (intermediate_scene.rs:1069-1072); Sampler / PixelFilter and all
 // Integrator parameters are ignored (scene.rs:120-128).
 // Not supported (returns RENE_ERR_UNSUPPORTED, never a silent fallback): blackbody / spectrum
-// colours, loopsubdiv, EXR and LDR image files (out of scope).
+// colours, EXR and JPEG image files (out of scope).
 #include <zlib.h>
 #include <algorithm>
 #include <cmath>
@@ -30,6 +30,7 @@
 
 namespace rene {
 void set_last_error(const std::string& msg);  // rene_hip.cpp: the thread-local behind rene_last_error()
+std::string loop_subdivide(std::vector<rene_vertex>& verts, std::vector<uint32_t>& idx, unsigned levels);  // loop_subdiv.cpp
 }
 
 namespace {
@@ -1360,7 +1361,6 @@ struct Builder {
         inst.mesh_index = -1;
         affine12(round32(mul(st.ctm, from_scale(s3))), inst.matrix);
       } else if (o.t == "trianglemesh" || o.t == "loopsubdiv") {  // intermediate_scene.rs:922-996
-        if (o.t == "loopsubdiv") unsupported("Shape \"loopsubdiv\" (OpenSubdiv)");
         const Value* iv = o.get("indices");
         const Value* pv = o.get("P");
         if (!iv) fail(RENE_ERR_INVALID_SCENE, "Argument not found indices");
@@ -1388,6 +1388,13 @@ struct Builder {
         for (size_t i = 0; i < idx.size(); ++i) {
           idx[i] = (uint32_t)iv->i[i];
           if (idx[i] >= nvert) fail(RENE_ERR_INVALID_SCENE, "trianglemesh index out of range");
+        }
+        if (o.t == "loopsubdiv") {  // intermediate_scene.rs:985-990, subdivision.rs:25-76
+          int nlevels = 0;
+          if (!get_int(o, "nlevels", nlevels)) fail(RENE_ERR_INVALID_SCENE, "Argument not found nlevels");
+          if (nlevels < 0 || nlevels > 10) fail(RENE_ERR_INVALID_SCENE, "loopsubdiv nlevels out of range (0..10)");
+          std::string why = rene::loop_subdivide(verts, idx, (unsigned)nlevels);
+          if (!why.empty()) fail(RENE_ERR_INVALID_SCENE, why);
         }
         inst.shape = RENE_SHAPE_TRIANGLE;
         inst.mesh_index = (int32_t)push_mesh(std::move(verts), std::move(idx));

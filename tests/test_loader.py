@@ -239,7 +239,7 @@ def test_errors(hip_lib):
         'Bogus 1 2 3': -7,
         'WorldBegin\nMaterial "matte" "rgb Kd" [1 2]\nWorldEnd': -7,
         'WorldBegin\nMaterial "matte" "blackbody Kd" [3000 1]\nWorldEnd': -4,
-        'WorldBegin\nShape "loopsubdiv" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd': -4,
+        'WorldBegin\nShape "loopsubdiv" "integer indices" [0 1 2] "point P" [0 0 0 1 0 0 0 1 0]\nWorldEnd': -2,  # nlevels is required (intermediate_scene.rs:986)
         'WorldBegin\nShape "plymesh" "string filename" "missing.ply"\nWorldEnd': -6,
         'Include "missing.pbrt"': -6,
     }
