@@ -15,6 +15,8 @@ struct LaunchConfig {
   uint32_t wave_stack = 0;   // wavefront integrator: LDS traversal stack entries per lane (exact tree depth)
 };
 
+// workgroups of the calling thread's most recent persistent render launch after fit_grid's clamp (rene_hip.cpp)
+extern thread_local uint32_t g_launched_blocks;
 hipError_t launch_render(const LaunchConfig& cfg, const SceneView& S, const RenderParams& P, hipStream_t st);
 hipError_t launch_render_bvh(const LaunchConfig& cfg, const SceneView& S, const RenderParams& P, hipStream_t st);
 hipError_t launch_render_vol(const LaunchConfig& cfg, const SceneView& S, const RenderParams& P, hipStream_t st);

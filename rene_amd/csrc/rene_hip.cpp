@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -55,12 +56,21 @@ struct HostPcg {
 
 namespace rene {
 void set_last_error(const std::string& msg) { g_error = msg; }
+thread_local uint32_t g_launched_blocks = 0;
 }
 
 struct rene_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  // RENE_FLAG_OVERLAP: consecutive launches alternate between `stream` and `stream2`, so that a launch starts
+  // filling the chip while the previous one drains its longest paths (its own work counter each; the kernels
+  // order the two launches' updates of a pixel through item_done[], device_code.inc item_publish / item_ready)
+  hipStream_t stream2 = nullptr;
+  hipEvent_t join_event = nullptr;
+  uint32_t* d_work_counter2 = nullptr;
+  uint32_t* h_resident = nullptr;   // pinned, one word per wave of a launch (RenderParams::resident)
+  uint32_t resident_words = 0;
   rene_opts opts{};
   std::vector<void*> allocations;
   rene::SceneView view{};
@@ -81,7 +91,18 @@ struct rene_ctx {
   struct Pending {
     hipEvent_t start, stop;
     uint32_t* d_seeds;
+    bool second_stream;
+    uint32_t epoch, waves;
   };
+  bool overlap() const { return stream2 != nullptr; }
+  // order everything launched on stream2 before whatever is enqueued on `stream` next (callers that handed in their
+  // own stream consume the framebuffer there)
+  hipError_t join() {
+    if (!stream2) return hipSuccess;
+    hipError_t e = hipEventRecord(join_event, stream2);
+    if (e == hipSuccess) e = hipStreamWaitEvent(stream, join_event, 0);
+    return e;
+  }
   std::deque<Pending> pending;
   uint64_t frames = 0, launches = 0;
   double kernel_ms = 0.0, last_ms = 0.0;
@@ -101,8 +122,35 @@ struct rene_ctx {
     return RENE_OK;
   }
 
-  int drain() {  // wait for the stream and fold finished launches into the timing totals
+  // RENE_FLAG_OVERLAP, before a launch is submitted to one of the two streams: (1) the previous launch on that stream
+  // has completed -- stream order would see to that, but the host must not run further ahead either; (2) every wave
+  // of the launch before this one (the other stream's) is resident, or that launch is over.  The new launch can then
+  // only be given the slots its predecessor's waves vacate.  Without (2) two launches submitted to an idle device
+  // start together, the later one may take every slot and wait there for pixels the earlier one can no longer reach.
+  int admit(bool second_stream) {
+    const Pending* same = nullptr;
+    for (auto it = pending.rbegin(); it != pending.rend(); ++it)
+      if (it->second_stream == second_stream) { same = &*it; break; }
+    if (same) HIP_TRY(hipEventSynchronize(same->stop));
+    if (pending.empty() || pending.back().second_stream == second_stream) return RENE_OK;
+    const Pending& prev = pending.back();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spins = 0;; ++spins) {
+      bool all = true;
+      for (uint32_t w = 0; w < prev.waves && all; ++w)
+        all = __atomic_load_n(&h_resident[w], __ATOMIC_ACQUIRE) == prev.epoch;
+      if (all) return RENE_OK;
+      if ((spins & 63u) == 63u) {
+        if (hipEventQuery(prev.stop) == hipSuccess) return RENE_OK;  // it has come and gone
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20))
+          return fail(RENE_ERR_DEVICE, "overlapping launches: the previous launch did not become resident");
+      }
+    }
+  }
+
+  int drain() {  // wait for the stream(s) and fold finished launches into the timing totals
     HIP_TRY(hipStreamSynchronize(stream));
+    if (stream2) HIP_TRY(hipStreamSynchronize(stream2));
     while (!pending.empty()) {
       Pending& p = pending.front();
       float ms = 0.0f;
@@ -329,8 +377,16 @@ int rene_create(const rene_scene_desc* scene, const rene_opts* opts, rene_ctx** 
   }
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_work_counter), sizeof(uint32_t)));
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_counters), 16 * sizeof(unsigned long long)));
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_item_done), std::max<size_t>(1, c->n_work) * sizeof(uint32_t)));
-  HIP_TRY(hipMemsetAsync(c->d_item_done, 0, std::max<size_t>(1, c->n_work) * sizeof(uint32_t), c->stream));
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_item_done), std::max<size_t>(1, c->n_work) * 2 * sizeof(uint32_t)));
+  HIP_TRY(hipMemsetAsync(c->d_item_done, 0, std::max<size_t>(1, c->n_work) * 2 * sizeof(uint32_t), c->stream));
+  if ((o.flags & RENE_FLAG_OVERLAP) && !c->wavefront) {
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->join_event, hipEventDisableTiming));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_work_counter2), sizeof(uint32_t)));
+    c->resident_words = c->cfg.grid * (uint32_t)(rene::render_block_size() / 64);
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_resident), c->resident_words * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(c->h_resident, 0, c->resident_words * sizeof(uint32_t));
+  }
   HIP_TRY(hipMemsetAsync(c->fb, 0, c->fb_floats * sizeof(float), c->stream));  // main.rs:1229-1237
   HIP_TRY(hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -344,6 +400,7 @@ void rene_destroy(rene_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
+  if (c->stream2) hipStreamSynchronize(c->stream2);
   for (auto& p : c->pending) {
     hipEventDestroy(p.start);
     hipEventDestroy(p.stop);
@@ -352,9 +409,13 @@ void rene_destroy(rene_ctx* c) {
   for (void* p : c->allocations) hipFree(p);
   if (c->own_fb && c->fb) hipFree(c->fb);
   if (c->d_work_counter) hipFree(c->d_work_counter);
+  if (c->d_work_counter2) hipFree(c->d_work_counter2);
+  if (c->join_event) hipEventDestroy(c->join_event);
+  if (c->stream2) hipStreamDestroy(c->stream2);
   if (c->d_counters) hipFree(c->d_counters);
   if (c->d_item_done) hipFree(c->d_item_done);
   if (c->h_done) hipHostFree(c->h_done);
+  if (c->h_resident) hipHostFree(c->h_resident);
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
   delete c;
 }
@@ -378,11 +439,23 @@ int rene_render(rene_ctx* c, uint32_t first_frame, uint32_t n_frames) {
   c->frames += n_frames;
   if (seeds.empty() || c->n_work == 0) return RENE_OK;
 
+  if (c->epoch == 0xffffffffu) {  // the hand-off flags are cleared when the epoch wraps: nothing may be in flight then
+    int rc = c->drain();
+    if (rc != RENE_OK) return rc;
+  }
+  // odd launches of an overlapping context go to the second stream, with the second work counter
+  const bool second_stream = c->overlap() && (c->epoch & 1u);
+  if (c->overlap()) {
+    int rc = c->admit(second_stream);
+    if (rc != RENE_OK) return rc;
+  }
+  hipStream_t stream = second_stream ? c->stream2 : c->stream;
+  uint32_t* work_counter = second_stream ? c->d_work_counter2 : c->d_work_counter;
   rene_ctx::Pending pend{};
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&pend.d_seeds), seeds.size() * sizeof(uint32_t)));
   // pageable source: the copy is staged before hipMemcpyAsync returns, so `seeds` may die
-  hipError_t e = hipMemcpyAsync(pend.d_seeds, seeds.data(), seeds.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
-  if (e == hipSuccess) e = hipMemsetAsync(c->d_work_counter, 0, sizeof(uint32_t), c->stream);
+  hipError_t e = hipMemcpyAsync(pend.d_seeds, seeds.data(), seeds.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream);
+  if (e == hipSuccess) e = hipMemsetAsync(work_counter, 0, sizeof(uint32_t), stream);
   if (e == hipSuccess) e = hipEventCreate(&pend.start);
   if (e == hipSuccess) e = hipEventCreate(&pend.stop);
   if (e != hipSuccess) {
@@ -392,7 +465,8 @@ int rene_render(rene_ctx* c, uint32_t first_frame, uint32_t n_frames) {
   rene::RenderParams P{};
   P.framebuffer = c->fb;
   P.seeds = pend.d_seeds;
-  P.work_counter = c->d_work_counter;
+  P.work_counter = work_counter;
+  P.resident = c->h_resident;  // host-coherent memory: the same pointer is valid on the device
   P.counters = c->d_counters;
   P.n_frames = (uint32_t)seeds.size();
   P.n_work = c->n_work;
@@ -401,13 +475,16 @@ int rene_render(rene_ctx* c, uint32_t first_frame, uint32_t n_frames) {
   P.tiles_x = c->tiles_x;
   P.n_tiles = c->n_tiles;
   P.flags = c->opts.flags;
+  if (c->overlap()) P.flags |= RENE_FLAG_DYNAMIC_FIRST;  // no work item may belong to a wave that is not resident yet
   P.two_level = (P.n_frames >= 4 && !(c->opts.flags & RENE_FLAG_SINGLE_LEVEL)) ? 1u : 0u;
   P.split_div = 4;
   if (const char* e = std::getenv("RENE_SPLIT_DIV")) P.split_div = (uint32_t)std::max(2, std::min(64, std::atoi(e)));  // tuning knob
   if (P.n_frames / P.split_div == 0) P.split_div = P.n_frames;  // the short item needs at least one frame
+  P.prev_epoch = c->epoch;
   if (++c->epoch == 0) {  // the flag array never needs clearing between launches unless the epoch wraps
-    hipMemsetAsync(c->d_item_done, 0, std::max<size_t>(1, c->n_work) * sizeof(uint32_t), c->stream);
+    hipMemsetAsync(c->d_item_done, 0, std::max<size_t>(1, c->n_work) * 2 * sizeof(uint32_t), stream);
     c->epoch = 1;
+    P.prev_epoch = 0;
   }
   P.epoch = c->epoch;
   P.item_done = c->d_item_done;
@@ -457,9 +534,13 @@ int rene_render(rene_ctx* c, uint32_t first_frame, uint32_t n_frames) {
   const uint32_t waves = cfg.grid * (uint32_t)(rene::render_block_size() / 64);
   P.work_batch = 128;
   while (P.work_batch > 16 && (uint64_t)P.work_batch * waves * 2u > total_items) P.work_batch >>= 1;
-  hipEventRecord(pend.start, c->stream);
-  e = rene::launch_render(cfg, c->view, P, c->stream);
-  hipEventRecord(pend.stop, c->stream);
+  hipEventRecord(pend.start, stream);
+  rene::g_launched_blocks = cfg.grid;
+  e = rene::launch_render(cfg, c->view, P, stream);
+  hipEventRecord(pend.stop, stream);
+  pend.second_stream = second_stream;
+  pend.epoch = P.epoch;
+  pend.waves = std::min(rene::g_launched_blocks * (uint32_t)(rene::render_block_size() / 64), c->resident_words);
   c->pending.push_back(pend);
   c->launches++;
   if (e != hipSuccess) return fail(RENE_ERR_DEVICE, std::string("render launch: ") + hipGetErrorString(e));
@@ -492,6 +573,10 @@ int rene_framebuffer(rene_ctx* c, void** device_ptr, size_t* n_floats) {
   if (!c || !device_ptr) return fail(RENE_ERR_INVALID_ARGUMENT, "rene_framebuffer: NULL argument");
   *device_ptr = c->fb;
   if (n_floats) *n_floats = c->fb_floats;
+  if (c->overlap()) {  // what the caller enqueues on the context's stream next comes after every launch
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(c->join());
+  }
   return RENE_OK;
 }
 

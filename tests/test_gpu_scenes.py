@@ -153,3 +153,39 @@ def test_wavefront_equals_megakernels_bit_for_bit(name):
             r.render(0, 7)
             acc += r.download(0)
     np.testing.assert_array_equal(acc, imgs[0][0])
+
+
+@pytest.mark.parametrize("name", ["cornell", "cornell-bvh", "veach", "dragon", "teapot", "fog", "zoo", "zoo-bvh", "media-zoo"])
+def test_overlapping_launches_are_bit_identical(name):
+    """RENE_FLAG_OVERLAP: consecutive launches alternate between two streams, so a launch starts while the previous
+    one is still draining its longest paths.  A pixel's running sums pass from launch to launch through the
+    item_done[] flags on the device (item_publish / item_ready), so the order of additions -- and every bit of
+    the three layers and the counters -- is the one of back-to-back launches on one stream."""
+    s, flags = {"cornell": (lambda: scenes.cornell_box(256, 256), 0),
+                "cornell-bvh": (lambda: scenes.cornell_box(128, 128), abi.FLAG_FORCE_BVH | abi.FLAG_NO_RESTART),
+                "veach": (lambda: scenes.veach_mis(192, 128), 0),
+                "dragon": (lambda: scenes.dragon_class(192, 108, 40, 44), 0),
+                "teapot": (lambda: scenes.teapot_class(192, 108, 20, 22), 0),
+                "fog": (lambda: scenes.cornell_fog(128, 128), 0),
+                "zoo": (lambda: scenes.material_zoo(128, 96), 0),  # multi-lobe kernels: two waves per SIMD, private scratch
+                "zoo-bvh": (lambda: scenes.material_zoo(128, 96), abi.FLAG_FORCE_BVH),
+                "media-zoo": (lambda: scenes.media_zoo(96, 64), 0)}[name]
+    s = s()
+    launches = [(0, 16), (16, 16), (32, 3), (35, 1), (36, 8), (44, 20)]  # two-level and single-level launches mixed
+    out = []
+    for extra in (0, abi.FLAG_OVERLAP):
+        with api.Renderer(s, flags=flags | abi.FLAG_COUNTERS | extra) as r:
+            for f0, nf in launches:
+                r.render(f0, nf)
+            imgs = [r.download(k) for k in range(3)]
+            out.append((imgs, r.stats().as_dict()))
+            # a second batch after the join: the flags of the first batch are what its first items wait for
+            r.render(64, 5)
+            r.render(69, 5)
+            out[-1] = (imgs + [r.download(0)], out[-1][1])
+    (a, sa), (b, sb) = out
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
+    for k in ("rays_closest", "rays_shadow", "rays_emitter", "paths", "hits", "adds", "launches", "frames"):
+        assert sa[k] == sb[k], k
+    assert np.isfinite(a[0]).all() and a[0].sum() > 0

@@ -3,15 +3,26 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rene_amd import scenes, api, abi
 
+OVERLAP = abi.FLAG_OVERLAP if os.environ.get("RENE_DEV_OVERLAP") == "1" else 0  # two launches in flight
+
+
 def run(name, s, F, reps=3):
-    r = api.Renderer(s)
+    if OVERLAP:
+        reps = 6
+    r = api.Renderer(s, flags=OVERLAP)
     r.render(0, 4); r.sync(); r.reset()
+    t0 = time.perf_counter()
     for k in range(reps):
         r.render(k * F, F)
     r.sync()
+    wall = time.perf_counter() - t0
     st = r.stats()
     with api.Renderer(s, flags=abi.FLAG_COUNTERS) as rc:
         rc.render(0, 2); c = rc.stats()
+    if OVERLAP:  # launches overlap: their event durations add up to more than the wall time
+        print(f"{name} [overlapped launches, wall clock]: {st.rays/wall/1e6:.0f} Mrays/s, {wall*1e3/st.frames:.3f} ms/frame", flush=True)
+        r.close()
+        return
     print(f"{name}: {st.rays/st.kernel_ms/1e3:.0f} Mrays/s, {st.kernel_ms/st.frames:.3f} ms/frame, rays/path {st.rays/st.paths:.2f}, "
           f"B_alg/ray {abi.algorithmic_bytes(c)/c.rays:.0f}, features {api.pack_info(s).features}", flush=True)
     r.close()
