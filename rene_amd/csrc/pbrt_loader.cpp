@@ -12,7 +12,7 @@
 // integrators select volpath (intermediate_scene.rs:1069-1072); Sampler / PixelFilter and all
 // Integrator parameters are ignored (scene.rs:120-128).
 // Not supported (returns RENE_ERR_UNSUPPORTED, never a silent fallback): blackbody / spectrum
-// colours, EXR and JPEG image files (out of scope).
+// colours, JPEG image files (out of scope).
 #include <zlib.h>
 #include <algorithm>
 #include <cmath>
@@ -31,6 +31,10 @@
 namespace rene {
 void set_last_error(const std::string& msg);  // rene_hip.cpp: the thread-local behind rene_last_error()
 std::string loop_subdivide(std::vector<rene_vertex>& verts, std::vector<uint32_t>& idx, unsigned levels);  // loop_subdiv.cpp
+// image_io.cpp: rows top first; LDR decoders give RGBA8, the EXR one linear f32
+bool decode_tga(const std::string& data, uint32_t& w, uint32_t& h, std::vector<unsigned char>& rgba, std::string& err);
+bool decode_bmp(const std::string& data, uint32_t& w, uint32_t& h, std::vector<unsigned char>& rgba, std::string& err);
+bool decode_exr(const std::string& data, uint32_t& w, uint32_t& h, std::vector<float>& rgba, std::string& err);
 }
 
 namespace {
@@ -876,6 +880,9 @@ struct Builder {
       rgba[i * 4 + 2] = inverse_gamma_correct((float)b / 255.0f);
       rgba[i * 4 + 3] = (float)a / 255.0f;
     }
+    return push_image(std::move(rgba), w, h);
+  }
+  uint32_t push_image(std::vector<float>&& rgba, uint32_t w, uint32_t h) {
     sc.image_data.push_back(std::move(rgba));
     rene_image im{};
     im.rgba = sc.image_data.back().data();
@@ -891,6 +898,26 @@ struct Builder {
     size_t dot = path.rfind('.');
     std::string ext = dot == std::string::npos ? "" : path.substr(dot + 1);
     if (ext == "png") return load_png(path, file);
+    if (ext == "tga" || ext == "bmp") {  // the `image` crate branch, intermediate_scene.rs:657-675
+      std::string bytes = read_file(path), why;
+      uint32_t w = 0, h = 0;
+      std::vector<unsigned char> px;
+      if (!(ext == "tga" ? rene::decode_tga(bytes, w, h, px, why) : rene::decode_bmp(bytes, w, h, px, why)))
+        fail(RENE_ERR_IO, (ext == "tga" ? "TGA" : "BMP") + std::string(" decode error (") + why + "): " + file);
+      std::vector<float> rgba((size_t)w * h * 4);
+      for (size_t i = 0; i < (size_t)w * h; ++i) {
+        for (int k = 0; k < 3; ++k) rgba[i * 4 + k] = inverse_gamma_correct((float)px[i * 4 + k] / 255.0f);
+        rgba[i * 4 + 3] = (float)px[i * 4 + 3] / 255.0f;
+      }
+      return push_image(std::move(rgba), w, h);
+    }
+    if (ext == "exr") {  // exr::prelude::read_first_rgba_layer_from_file, intermediate_scene.rs:641-656
+      std::string bytes = read_file(path), why;
+      uint32_t w = 0, h = 0;
+      std::vector<float> rgba;
+      if (!rene::decode_exr(bytes, w, h, rgba, why)) fail(RENE_ERR_IO, "EXR decode error (" + why + "): " + file);
+      return push_image(std::move(rgba), w, h);
+    }
     if (ext != "pfm") unsupported("image format ." + ext + " (" + file + ")");
     std::string data = read_file(path);
     // header: "PF\n<w> <h>\n<scale>\n" then rows bottom-to-top; negative scale = little endian

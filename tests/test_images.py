@@ -1,0 +1,292 @@
+"""Image files behind `Texture "imagemap"` / the infinite light (load_image, rene/src/scene/intermediate_scene.rs:631-677
+-> rene_amd/csrc/image_io.cpp): TGA and BMP through the LDR branch (RGBA8 -> inverse gamma), OpenEXR through the
+HDR branch.  The reference uses the `image` and `exr` crates, which are not in the checkout, and no reference test
+reads an image, so parity is unpinned; the decoders are checked against files written here by independent encoders
+(struct / numpy / zlib, straight from the format specifications) and -- when /root/reference is present -- against
+the reference's own PIZ-compressed EXR renders and their PNG companions."""
+import ctypes as C
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from rene_amd import api, loader
+from conftest import REFERENCE, have_reference
+
+
+def load(tmp_path, name):
+    text = f'WorldBegin\nTexture "t" "spectrum" "imagemap" "string filename" "{name}"\nMaterial "matte" "texture Kd" "t"\nShape "sphere"\nWorldEnd\n'
+    ls = loader.parse_pbrt(text, str(tmp_path))  # owns the tables desc points into
+    d = ls.desc
+    im = d.images[d.n_images - 1]
+    return np.frombuffer(C.string_at(im.rgba, im.height * im.width * 16), np.float32).reshape(im.height, im.width, 4).copy()
+
+
+def srgb_to_linear(v8):
+    v = np.asarray(v8, np.float32) / np.float32(255.0)
+    return np.where(v <= 0.04045, v / np.float32(12.92), ((v + np.float32(0.055)) / np.float32(1.055)) ** np.float32(2.4)).astype(np.float32)
+
+
+def expect_ldr(rgba8):
+    out = np.empty(rgba8.shape, np.float32)
+    out[..., :3] = srgb_to_linear(rgba8[..., :3])
+    out[..., 3] = rgba8[..., 3].astype(np.float32) / np.float32(255.0)
+    return out
+
+
+def _picture(h, w, seed):
+    rng = np.random.default_rng(seed)
+    img = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    img[: h // 2, : w // 2] = (200, 30, 90, 255)  # a flat patch so that run-length packets occur
+    return img
+
+
+# ------------------------------------------------------------------------------------------------ TGA
+def tga_bytes(img, kind, rle=False, top_down=False, id_bytes=b""):
+    h, w = img.shape[:2]
+    rows = img if top_down else img[::-1]
+    cmap = b""
+    if kind == "bgr":
+        px, depth, typ, cm = rows[..., [2, 1, 0]].reshape(-1, 3), 24, 2, (0, 0, 0, 0)
+    elif kind == "bgra":
+        px, depth, typ, cm = rows[..., [2, 1, 0, 3]].reshape(-1, 4), 32, 2, (0, 0, 0, 0)
+    elif kind == "grey":
+        px, depth, typ, cm = rows[..., :1].reshape(-1, 1), 8, 3, (0, 0, 0, 0)
+    elif kind == "grey-alpha":
+        px, depth, typ, cm = rows[..., [0, 3]].reshape(-1, 2), 16, 3, (0, 0, 0, 0)
+    else:  # colour map: quantise to 16 colours, first index 3
+        pal = np.array([[(37 * i) % 256, (91 * i) % 256, (53 * i) % 256] for i in range(16)], np.uint8)
+        idx = (rows[..., 0] % 16).astype(np.uint8)
+        px, depth, typ, cm = (idx + 3).reshape(-1, 1), 8, 1, (1, 3, 16, 24)
+        cmap = pal[:, ::-1].tobytes()
+    if rle:
+        typ += 8
+        body, i, n = bytearray(), 0, len(px)
+        while i < n:
+            run = 1
+            while i + run < n and run < 128 and (px[i + run] == px[i]).all():
+                run += 1
+            if run > 1:
+                body += bytes([0x80 | (run - 1)]) + px[i].tobytes()
+                i += run
+            else:
+                lit = 1
+                while i + lit < n and lit < 128 and not (i + lit + 1 < n and (px[i + lit] == px[i + lit + 1]).all()):
+                    lit += 1
+                body += bytes([lit - 1]) + px[i:i + lit].tobytes()
+                i += lit
+        body = bytes(body)
+    else:
+        body = px.tobytes()
+    desc = (0x20 if top_down else 0) | (8 if kind in ("bgra", "grey-alpha") else 0)
+    head = struct.pack("<BBBHHBHHHHBB", len(id_bytes), cm[0], typ, cm[1], cm[2], cm[3], 0, 0, w, h, depth, desc)
+    return head + id_bytes + cmap + body
+
+
+@pytest.mark.parametrize("kind", ["bgr", "bgra", "grey", "grey-alpha", "cmap"])
+@pytest.mark.parametrize("rle", [False, True])
+def test_tga(tmp_path, hip_lib, kind, rle):
+    img = _picture(13, 21, 3)
+    for top_down in (False, True):
+        (tmp_path / "a.tga").write_bytes(tga_bytes(img, kind, rle=rle, top_down=top_down, id_bytes=b"id" if rle else b""))
+        got = load(tmp_path, "a.tga")
+        want = img.copy()
+        if kind == "bgr":
+            want[..., 3] = 255
+        elif kind == "grey":
+            want = np.repeat(img[..., :1], 4, axis=2); want[..., 3] = 255
+        elif kind == "grey-alpha":
+            want = np.concatenate([np.repeat(img[..., :1], 3, axis=2), img[..., 3:]], axis=2)
+        elif kind == "cmap":
+            pal = np.array([[(37 * i) % 256, (91 * i) % 256, (53 * i) % 256] for i in range(16)], np.uint8)
+            want = np.concatenate([pal[img[..., 0] % 16], np.full(img.shape[:2] + (1,), 255, np.uint8)], axis=2)
+        np.testing.assert_allclose(got.reshape(13, 21, 4), expect_ldr(want), rtol=5e-7, atol=0)  # powf, last bit
+
+
+# ------------------------------------------------------------------------------------------------ BMP
+def bmp_bytes(img, bpp, top_down=False, bitfields=False):
+    h, w = img.shape[:2]
+    rows = img if top_down else img[::-1]
+    pal = b""
+    if bpp == 8:
+        palette = np.array([[(37 * i) % 256, (91 * i) % 256, (53 * i) % 256] for i in range(256)], np.uint8)
+        pal = np.concatenate([palette[:, ::-1], np.zeros((256, 1), np.uint8)], axis=1).tobytes()
+        px = rows[..., 0]
+    elif bpp == 24:
+        px = rows[..., [2, 1, 0]].reshape(h, -1)
+    else:
+        px = (rows[..., [3, 0, 1, 2]] if bitfields else rows[..., [2, 1, 0, 3]]).reshape(h, -1)  # masks below: A, R, G, B bytes
+    stride = (px.shape[1] + 3) // 4 * 4
+    body = b"".join(r.tobytes() + b"\0" * (stride - px.shape[1]) for r in px)
+    masks = struct.pack("<IIII", 0x0000ff00, 0x00ff0000, 0xff000000, 0x000000ff) if bitfields else b""
+    dib = struct.pack("<IiiHHIIiiII", 40 + (16 if bitfields else 0), w, -h if top_down else h, 1, bpp, 3 if bitfields else 0, len(body), 2835, 2835, 0, 0) + masks
+    off = 14 + len(dib) + len(pal)
+    return b"BM" + struct.pack("<IHHI", off + len(body), 0, 0, off) + dib + pal + body
+
+
+@pytest.mark.parametrize("bpp,bitfields", [(8, False), (24, False), (32, False), (32, True)])
+def test_bmp(tmp_path, hip_lib, bpp, bitfields):
+    img = _picture(9, 14, 4)
+    for top_down in (False, True):
+        (tmp_path / "a.bmp").write_bytes(bmp_bytes(img, bpp, top_down=top_down, bitfields=bitfields))
+        got = load(tmp_path, "a.bmp")
+        want = img.copy()
+        if bpp == 8:
+            palette = np.array([[(37 * i) % 256, (91 * i) % 256, (53 * i) % 256] for i in range(256)], np.uint8)
+            want = np.concatenate([palette[img[..., 0]], np.full(img.shape[:2] + (1,), 255, np.uint8)], axis=2)
+        elif not bitfields:
+            want[..., 3] = 255  # BI_RGB has no alpha
+        np.testing.assert_allclose(got.reshape(9, 14, 4), expect_ldr(want), rtol=5e-7, atol=0)
+
+
+# ------------------------------------------------------------------------------------------------ EXR
+def _attr(name, typ, value):
+    return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<i", len(value)) + value
+
+
+def exr_bytes(channels, h, w, compression, x0=0, y0=0):
+    """channels: {name: (array[h, w], 'half' | 'float' | 'uint')}.  Scan-line file, increasing y."""
+    names = sorted(channels)
+    tcode = {"uint": 0, "half": 1, "float": 2}
+    ndt = {"uint": "<u4", "half": "<f2", "float": "<f4"}
+    chlist = b"".join(n.encode() + b"\0" + struct.pack("<iBBBBii", tcode[channels[n][1]], 0, 0, 0, 0, 1, 1) for n in names) + b"\0"
+    box = struct.pack("<iiii", x0, y0, x0 + w - 1, y0 + h - 1)
+    head = struct.pack("<II", 20000630, 2)
+    head += _attr("channels", "chlist", chlist) + _attr("compression", "compression", bytes([compression]))
+    head += _attr("dataWindow", "box2i", box) + _attr("displayWindow", "box2i", box) + _attr("lineOrder", "lineOrder", b"\0")
+    head += _attr("pixelAspectRatio", "float", struct.pack("<f", 1)) + _attr("screenWindowCenter", "v2f", struct.pack("<ff", 0, 0))
+    head += _attr("screenWindowWidth", "float", struct.pack("<f", 1)) + b"\0"
+    lines = {0: 1, 1: 1, 2: 1, 3: 16}[compression]
+    blocks = []
+    for b0 in range(0, h, lines):
+        raw = b"".join(np.asarray(channels[n][0][y], ndt[channels[n][1]]).tobytes() for y in range(b0, min(h, b0 + lines)) for n in names)
+        data = raw
+        if compression in (1, 2, 3):
+            t = np.frombuffer(raw, np.uint8)
+            t = np.concatenate([t[0::2], t[1::2]])  # even bytes | odd bytes
+            d = t.astype(np.int32)
+            d[1:] = (d[1:] - d[:-1] + 128 + 256) % 256  # predictor
+            shuffled = d.astype(np.uint8).tobytes()
+            if compression == 1:
+                out, i = bytearray(), 0
+                while i < len(shuffled):
+                    run = 1
+                    while i + run < len(shuffled) and run < 128 and shuffled[i + run] == shuffled[i]:
+                        run += 1
+                    if run >= 3:
+                        out += struct.pack("b", run - 1) + shuffled[i:i + 1]
+                        i += run
+                    else:
+                        lit = 0
+                        while i + lit < len(shuffled) and lit < 127:
+                            if i + lit + 2 < len(shuffled) and shuffled[i + lit] == shuffled[i + lit + 1] == shuffled[i + lit + 2]:
+                                break
+                            lit += 1
+                        lit = max(lit, 1)
+                        out += struct.pack("b", -lit) + shuffled[i:i + lit]
+                        i += lit
+                data = bytes(out)
+            else:
+                data = zlib.compress(shuffled)
+            if len(data) >= len(raw):
+                data = raw  # the writers fall back to the raw block
+        blocks.append(struct.pack("<ii", y0 + b0, len(data)) + data)
+    table_at = len(head)
+    offs, at = [], table_at + 8 * len(blocks)
+    for b in blocks:
+        offs.append(at)
+        at += len(b)
+    return head + b"".join(struct.pack("<Q", o) for o in offs) + b"".join(blocks)
+
+
+@pytest.mark.parametrize("compression", [0, 1, 2, 3])
+def test_exr_scanline_compressions_and_channel_types(tmp_path, hip_lib, compression):
+    rng = np.random.default_rng(compression)
+    h, w = 37, 23  # not a multiple of the 16-line ZIP block
+    r = rng.random((h, w)).astype(np.float16)
+    r[:10] = np.float16(0.25)  # compressible rows
+    g = (rng.random((h, w)) * 100).astype(np.float32)
+    b = rng.integers(0, 70000, (h, w)).astype(np.uint32)
+    a = rng.random((h, w)).astype(np.float16)
+    r[0, 0], r[0, 1], r[0, 2] = np.float16(6e-8), np.float16(-0.0), np.float16(65504)  # subnormal, signed zero, largest half
+    chans = {"R": (r, "half"), "G": (g, "float"), "B": (b, "uint"), "A": (a, "half"), "Z": (g * 2, "float")}  # Z: ignored
+    (tmp_path / "a.exr").write_bytes(exr_bytes(chans, h, w, compression, x0=-5, y0=7))
+    got = load(tmp_path, "a.exr").reshape(h, w, 4)
+    np.testing.assert_array_equal(got[..., 0], r.astype(np.float32))
+    np.testing.assert_array_equal(got[..., 1], g)
+    np.testing.assert_array_equal(got[..., 2], b.astype(np.float32))
+    np.testing.assert_array_equal(got[..., 3], a.astype(np.float32))
+
+
+def test_exr_without_alpha_and_luminance_only(tmp_path, hip_lib):
+    rng = np.random.default_rng(9)
+    h, w = 5, 7
+    r, g, b = (rng.random((h, w)).astype(np.float16) for _ in range(3))
+    (tmp_path / "rgb.exr").write_bytes(exr_bytes({"R": (r, "half"), "G": (g, "half"), "B": (b, "half")}, h, w, 3))
+    got = load(tmp_path, "rgb.exr").reshape(h, w, 4)
+    np.testing.assert_array_equal(got[..., :3], np.stack([r, g, b], axis=2).astype(np.float32))
+    assert (got[..., 3] == 1.0).all()
+    (tmp_path / "y.exr").write_bytes(exr_bytes({"Y": (g, "half")}, h, w, 2))
+    got = load(tmp_path, "y.exr").reshape(h, w, 4)
+    for k in range(3):
+        np.testing.assert_array_equal(got[..., k], g.astype(np.float32))
+
+
+def test_image_errors(tmp_path, hip_lib):
+    good = exr_bytes({"R": (np.zeros((4, 4), np.float16), "half"), "G": (np.zeros((4, 4), np.float16), "half"), "B": (np.zeros((4, 4), np.float16), "half")}, 4, 4, 3)
+    cases = {"trunc.exr": good[:-7], "magic.exr": b"abcd" + good[4:], "tiled.exr": good[:4] + struct.pack("<I", 2 | 0x200) + good[8:],
+             "dwa.exr": good.replace(b"compression\0compression\0\x01\0\0\0\x03", b"compression\0compression\0\x01\0\0\0\x08"),
+             "trunc.tga": tga_bytes(_picture(4, 4, 1), "bgr")[:30], "type.tga": bytes([0, 0, 7]) + bytes(15),
+             "sig.bmp": b"XX" + bmp_bytes(_picture(4, 4, 1), 24)[2:], "short.bmp": bmp_bytes(_picture(4, 4, 1), 24)[:60]}
+    for name, blob in cases.items():
+        (tmp_path / name).write_bytes(blob)
+        with pytest.raises(api.ReneError) as e:
+            load(tmp_path, name)
+        assert e.value.code == -6 and "decode error" in str(e.value), (name, str(e.value))
+    (tmp_path / "a.jpg").write_bytes(b"\xff\xd8\xff")
+    with pytest.raises(api.ReneError) as e:
+        load(tmp_path, "a.jpg")
+    assert e.value.code == -4  # RENE_ERR_UNSUPPORTED, never a guess
+
+
+@pytest.mark.reference
+@pytest.mark.skipif(not have_reference(), reason="needs /root/reference/sample_scenes")
+@pytest.mark.parametrize("scene", ["cornell-box", "veach-mis"])
+def test_piz_against_the_reference_renders(tmp_path, hip_lib, scene):
+    """sample_scenes/*/TungstenRender.exr are PIZ-compressed half RGB files (written by Tungsten, not by rene);
+    TungstenRender.png next to each is the same render tone-mapped to 8 bits.  A PIZ decoder that is wrong
+    anywhere (Huffman table, run-length symbol, wavelet, value table) gives noise, so: the decoded image must be
+    finite and non-negative, and one rising tone curve must relate its values to the PNG's."""
+    d = os.path.join(REFERENCE, "sample_scenes", scene)
+    os.symlink(os.path.join(d, "TungstenRender.exr"), tmp_path / "t.exr")
+    os.symlink(os.path.join(d, "TungstenRender.png"), tmp_path / "t.png")
+    hdr = load(tmp_path, "t.exr")
+    ldr = load(tmp_path, "t.png")  # linear again: the loader applies inverse gamma
+    assert hdr.shape == ldr.shape
+    rgb, ref = hdr.reshape(-1, 4)[:, :3], ldr.reshape(-1, 4)[:, :3]
+    assert np.isfinite(rgb).all() and (rgb >= 0).all() and (hdr.reshape(-1, 4)[:, 3] == 1).all()
+    # the PNG is the EXR through one tone curve applied to every channel value: pooled over pixels and channels,
+    # samples of equal HDR value must share their LDR value, and the curve must rise
+    x, y = rgb.reshape(-1), ref.reshape(-1)
+    ok = (y > 0.02) & (y < 0.8) & (x > 1e-3)
+    assert ok.mean() > 0.2
+    order = np.argsort(x[ok])
+    n = len(order) // 64 * 64
+    yb = y[ok][order][:n].reshape(64, -1)
+    assert (yb.std(axis=1) / yb.mean(axis=1))[:-4].max() < 0.05  # the last bins span the sparse bright end of the curve
+    assert (np.diff(yb.mean(axis=1)) > 0).all()
+
+
+def test_tga_and_bmp_written_by_pil(tmp_path, hip_lib):
+    """A second, independent encoder: PIL's TGA (raw and RLE, RGB / RGBA / L) and BMP (RGB, palette) writers."""
+    from PIL import Image
+    img = _picture(11, 19, 8)
+    cases = {"rgb.tga": (Image.fromarray(img[..., :3], "RGB"), {}), "rgba_rle.tga": (Image.fromarray(img, "RGBA"), {"compression": "tga_rle"}),
+             "l_rle.tga": (Image.fromarray(img[..., 0], "L"), {"compression": "tga_rle"}), "rgb.bmp": (Image.fromarray(img[..., :3], "RGB"), {}),
+             "pal.bmp": (Image.fromarray(img[..., :3], "RGB").quantize(32), {})}
+    for name, (im, kw) in cases.items():
+        im.save(tmp_path / name, **kw)
+        want = np.asarray(Image.open(tmp_path / name).convert("RGBA"), dtype=np.uint8)
+        np.testing.assert_allclose(load(tmp_path, name), expect_ldr(want), rtol=5e-7, atol=0, err_msg=name)
