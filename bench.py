@@ -8,7 +8,12 @@ Workload: BASELINE.json configs[1], "Cornell-box 1024x1024 @ 1024 spp, 1x MI355X
 Cornell-box-shaped scene built in code, rene_amd/scenes.py).  A *step* is one launch of the
 persistent render kernel over every pixel this rank owns for `frames_per_step = ceil(1024 / K)`
 frames, so the K timed steps always render the full 1024 spp (a little more if K does not divide
-1024).  Inputs (scene tables, BVH, frame seeds) are resident in HBM before the timed region.
+1024).  Default K = 4, i.e. 256 frames per launch: a launch ends with its longest paths and a partly idle chip, so
+fewer, longer launches are the efficient way to ask for 1024 spp (measured, Grays/s at K = 16 / 8 / 4 / 2:
+82.6 / 86.8 / 91.2 / 88.0 -- at K = 2 there is no third launch to hide the second one's tail).  Consecutive
+launches overlap on two streams (RENE_FLAG_OVERLAP) and the work-item granularity is picked by rene_tune in the
+untimed part; neither changes a bit of the image.  Inputs (scene tables, BVH, frame seeds) are resident in HBM
+before the timed region.
 
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL).  Strong scaling: the job is still
 K steps = 1024 spp of the whole image; its K * frames_per_step frames are dealt to the ranks in N
@@ -75,14 +80,17 @@ def valu_issue(frames_per_step: int, n_gpus: int, launch_ms: float, cus: int, cl
     avail = cus * 4 * launch_ms * 1e-3 * clock_ghz * 1e9
     return {"valu_wave_insts_per_launch": insts, "issue_cycles_frac": insts * 4.0 / avail,
             "lane_ops_per_ray": None, "clock_ghz": clock_ghz, "cus": cus,
-            "source": f"profiles/{rec.get('tag', '')}_pmc.txt (SQ_INSTS_VALU) / live launch period"}
+            "source": f"profiles/{rec.get('tag', '')}_pmc.txt (SQ_INSTS_VALU) / live launch period",
+            "model": "4 issue cycles per wave64 VALU instruction at the nominal clock; a fraction above 1 says the hardware "
+                     "retires some of them faster (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.03 quad-cycles per instruction "
+                     "over a launch that is not busy throughout) -- the issue slots are full either way"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--cpu-spp", type=int, default=128, help="frames of the CPU-oracle baseline sample (~10 s on 16 threads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -142,6 +150,9 @@ def main():
         rc.render(0, cf)
         cst = rc.stats()
     bytes_per_ray = abi.algorithmic_bytes(cst) / max(1, cst.rays)
+
+    # ---- untimed: work-item granularity for launches of F frames (rene_tune; no bit of the image depends on it) ----
+    r.tune(F)
 
     # ---- warmup (kernel + the collective: RCCL sets its rings up lazily), then a clean image ----
     for k in range(Wm):

@@ -278,6 +278,14 @@ int rene_download(rene_ctx* ctx, int layer, int channels, float* dst, size_t dst
 /* Zero the accumulation layers and the counters (main.rs:1229-1237). */
 int rene_reset(rene_ctx* ctx);
 
+/* Optional, before rendering: picks how finely a launch of `n_frames` frames cuts a pixel's frames into work items
+ * (no reference counterpart; rene dispatches one frame at a time, main.rs:1355-1372).  Few, long items cost the
+ * least bookkeeping; short ones balance scenes whose pixels differ widely in cost (a 16-frame launch of the
+ * dragon-class scene: 6.0 Grays/s with one item per pixel, 7.9 with eight).  Renders a few launches of
+ * `n_frames` frames per candidate, keeps the fastest, then resets the context like rene_reset.  The choice changes
+ * no bit of any image -- a pixel's frames are added in the same order however they are cut. */
+int rene_tune(rene_ctx* ctx, uint32_t n_frames);
+
 /* Device address of the accumulation image [3][yres][xres][4] f32 (for an RCCL reduce by the host). */
 int rene_framebuffer(rene_ctx* ctx, void** device_ptr, size_t* n_floats);
 

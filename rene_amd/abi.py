@@ -142,7 +142,7 @@ def algorithmic_bytes(stats) -> int:
 
 # every symbol include/rene_hip.h declares (tests check that the shared library exports them all)
 EXPORTED_SYMBOLS = [
-    "rene_create", "rene_render", "rene_sync", "rene_download", "rene_reset", "rene_framebuffer",
+    "rene_create", "rene_render", "rene_sync", "rene_download", "rene_reset", "rene_tune", "rene_framebuffer",
     "rene_get_stats", "rene_trace", "rene_bsdf_eval", "rene_medium_eval", "rene_destroy", "rene_scene_pack_info", "rene_last_error", "rene_abi_version",
     "rene_to_rgb8", "rene_to_aov8", "rene_frame_seeds",
     "rene_scene_load_pbrt", "rene_scene_parse_pbrt", "rene_scene_get_desc",

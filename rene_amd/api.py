@@ -55,6 +55,7 @@ def lib():
     L.rene_sync.argtypes = [vp]
     L.rene_download.argtypes = [vp, i32, i32, vp, C.c_size_t]
     L.rene_reset.argtypes = [vp]
+    L.rene_tune.argtypes = [vp, C.c_uint32]
     L.rene_framebuffer.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.rene_get_stats.argtypes = [vp, C.POINTER(abi.Stats)]
     L.rene_trace.argtypes = [vp, i32, C.c_size_t, vp, vp, C.c_float, C.c_float, vp]
@@ -139,6 +140,10 @@ class Renderer:
 
     def reset(self):
         _check(lib().rene_reset(self._h))
+
+    def tune(self, n_frames: int):
+        """rene_tune: pick the work-item granularity for launches of n_frames frames; resets the image."""
+        _check(lib().rene_tune(self._h, n_frames))
 
     def download(self, layer: int = abi.LAYER_RADIANCE, channels: int = 3) -> np.ndarray:
         out = np.empty((self.yres, self.xres, channels), dtype=np.float32)

@@ -217,16 +217,17 @@ struct RenderParams {
   uint32_t shard_rank, shard_count;  // tile sharding (shard_count == 1: all tiles)
   uint32_t tiles_x, n_tiles;
   uint32_t flags;
-  uint32_t two_level;      // 1: every pixel is cut into a long and a short work item (ordered hand-off)
-  uint32_t epoch;          // launch number (>= 1): value a long item publishes in item_done[]
-  uint32_t* item_done;     // [2 * n_work] per-pixel hand-off flags: long item done, last item done (item_publish)
+  uint32_t n_levels;       // every pixel's frames are cut into n_levels work items of level_step frames (ordered hand-off)
+  uint32_t epoch;          // launch number (1 .. 2^27 - 1)
+  uint32_t* item_done;     // [n_work] per-pixel hand-off flags: epoch << 5 | items of the pixel committed so far (item_publish)
   uint32_t ready_min;      // traversal-restart kernel: lanes waiting before the logic step runs
   uint32_t leaf_min;       // traversal-restart kernel: lanes at a leaf before the leaf step runs
-  uint32_t split_div;      // the short item of a pixel covers the last n_frames / split_div frames (4)
+  uint32_t level_step;     // frames per work item: item (level, pixel) renders frames [level * step, min(F, (level + 1) * step))
   uint32_t static_waves;   // waves whose first batch is assigned statically (<= co-resident waves)
   uint32_t work_batch;     // work ids a wave takes per global atomic: 128 when items are plentiful, fewer
                            // (down to 16) when a launch has too few items to give every wave a full batch
-  uint32_t prev_epoch;     // epoch of the context's previous launch (0: none): what a pixel's first item waits for
+  uint32_t prev_final;     // item_done[] value the context's previous launch leaves behind (0: none): what a pixel's
+                           // first item waits for
   uint32_t* resident;      // RENE_FLAG_OVERLAP: host-visible [waves]; every wave stores `epoch` here when it starts, so the
                            // host can tell that the whole launch is resident before it submits the next one (else null)
 };

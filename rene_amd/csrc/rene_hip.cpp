@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -81,7 +82,8 @@ struct rene_ctx {
   size_t fb_floats = 0;
   uint32_t* d_work_counter = nullptr;
   uint32_t* d_item_done = nullptr;
-  uint32_t epoch = 0;
+  uint32_t epoch = 0, prev_final = 0;
+  uint32_t item_frames = 0;  // frames per work item; 0 = one item per pixel and launch (rene_tune picks)
   unsigned long long* d_counters = nullptr;
   // stage-separated wavefront integrator (BVH scenes): path state in HBM + a pinned word for the host loop
   bool wavefront = false;
@@ -377,8 +379,8 @@ int rene_create(const rene_scene_desc* scene, const rene_opts* opts, rene_ctx** 
   }
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_work_counter), sizeof(uint32_t)));
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_counters), 16 * sizeof(unsigned long long)));
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_item_done), std::max<size_t>(1, c->n_work) * 2 * sizeof(uint32_t)));
-  HIP_TRY(hipMemsetAsync(c->d_item_done, 0, std::max<size_t>(1, c->n_work) * 2 * sizeof(uint32_t), c->stream));
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_item_done), std::max<size_t>(1, c->n_work) * sizeof(uint32_t)));
+  HIP_TRY(hipMemsetAsync(c->d_item_done, 0, std::max<size_t>(1, c->n_work) * sizeof(uint32_t), c->stream));
   if ((o.flags & RENE_FLAG_OVERLAP) && !c->wavefront) {
     HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&c->join_event, hipEventDisableTiming));
@@ -439,7 +441,7 @@ int rene_render(rene_ctx* c, uint32_t first_frame, uint32_t n_frames) {
   c->frames += n_frames;
   if (seeds.empty() || c->n_work == 0) return RENE_OK;
 
-  if (c->epoch == 0xffffffffu) {  // the hand-off flags are cleared when the epoch wraps: nothing may be in flight then
+  if (c->epoch >= (1u << 27) - 1u) {  // the hand-off flags are cleared when the epoch wraps: nothing may be in flight then
     int rc = c->drain();
     if (rc != RENE_OK) return rc;
   }
@@ -476,17 +478,21 @@ int rene_render(rene_ctx* c, uint32_t first_frame, uint32_t n_frames) {
   P.n_tiles = c->n_tiles;
   P.flags = c->opts.flags;
   if (c->overlap()) P.flags |= RENE_FLAG_DYNAMIC_FIRST;  // no work item may belong to a wave that is not resident yet
-  P.two_level = (P.n_frames >= 4 && !(c->opts.flags & RENE_FLAG_SINGLE_LEVEL)) ? 1u : 0u;
-  P.split_div = 4;
-  if (const char* e = std::getenv("RENE_SPLIT_DIV")) P.split_div = (uint32_t)std::max(2, std::min(64, std::atoi(e)));  // tuning knob
-  if (P.n_frames / P.split_div == 0) P.split_div = P.n_frames;  // the short item needs at least one frame
-  P.prev_epoch = c->epoch;
-  if (++c->epoch == 0) {  // the flag array never needs clearing between launches unless the epoch wraps
-    hipMemsetAsync(c->d_item_done, 0, std::max<size_t>(1, c->n_work) * 2 * sizeof(uint32_t), stream);
-    c->epoch = 1;
-    P.prev_epoch = 0;
+  // every pixel's frames in `levels` work items of `step` frames (device_code.inc, render_kernel)
+  uint32_t levels = c->item_frames ? std::min(31u, (P.n_frames + c->item_frames - 1) / c->item_frames) : 1u;
+  if (const char* e = std::getenv("RENE_LEVELS")) levels = (uint32_t)std::max(1, std::min(31, std::atoi(e)));  // tuning knob
+  if ((c->opts.flags & RENE_FLAG_SINGLE_LEVEL) || P.n_frames < 4) levels = 1;
+  levels = std::min(levels, P.n_frames);
+  P.level_step = (P.n_frames + levels - 1) / levels;
+  P.n_levels = (P.n_frames + P.level_step - 1) / P.level_step;
+  P.prev_final = c->prev_final;
+  if (c->epoch >= (1u << 27) - 1u) {  // (drained above) the flag array never needs clearing unless the epoch wraps
+    hipMemsetAsync(c->d_item_done, 0, std::max<size_t>(1, c->n_work) * sizeof(uint32_t), stream);
+    c->epoch = 0;
+    P.prev_final = 0;
   }
-  P.epoch = c->epoch;
+  P.epoch = ++c->epoch;
+  c->prev_final = (P.epoch << 5) | P.n_levels;
   P.item_done = c->d_item_done;
   // swept with the BVH4 (tools/dev_sweep4.py): dragon-class (Matte) peaks at 24 / 12 (4.96 Grays/s; 20 / 16 gave 4.6);
   // teapot-class, whose logic step is the general-BSDF one, keeps gaining up to ~44 waiting lanes (5.3 vs 4.7)
@@ -528,7 +534,7 @@ int rene_render(rene_ctx* c, uint32_t first_frame, uint32_t n_frames) {
   rene::LaunchConfig cfg = c->cfg;
   // launch no more lanes than there are work items; hand items out in batches small enough that every
   // launched wave gets some (a tile shard of a small image has fewer items than the chip has lanes)
-  const uint32_t total_items = P.two_level ? 2u * c->n_work : c->n_work;
+  const uint32_t total_items = P.n_levels * c->n_work;
   uint32_t blocks_needed = (total_items + rene::render_block_size() - 1) / rene::render_block_size();
   cfg.grid = std::max(1u, std::min(cfg.grid, blocks_needed));
   const uint32_t waves = cfg.grid * (uint32_t)(rene::render_block_size() / 64);
@@ -567,6 +573,35 @@ int rene_reset(rene_ctx* c) {
   c->kernel_ms = 0.0;
   c->last_ms = 0.0;
   return RENE_OK;
+}
+
+int rene_tune(rene_ctx* c, uint32_t n_frames) {
+  if (!c) return fail(RENE_ERR_INVALID_ARGUMENT, "rene_tune: NULL context");
+  if (c->wavefront || n_frames < 4 || c->n_work == 0 || (c->opts.flags & RENE_FLAG_SINGLE_LEVEL)) return RENE_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  int rc = c->drain();
+  if (rc != RENE_OK) return rc;
+  const uint32_t saved = c->item_frames;
+  uint32_t best = saved;
+  double best_ms = 0.0;
+  for (uint32_t levels = 1; levels <= 16 && levels <= n_frames; levels *= 2) {
+    c->item_frames = levels == 1 ? 0u : (n_frames + levels - 1) / levels;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int k = 0; k < 4 && rc == RENE_OK; ++k) rc = rene_render(c, 0, n_frames);  // what is rendered does not matter
+    if (rc == RENE_OK) rc = c->drain();
+    if (rc != RENE_OK) {
+      c->item_frames = saved;
+      return rc;
+    }
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (levels == 1 || ms < 0.985 * best_ms) {  // finer items must pay for their bookkeeping
+      best_ms = ms;
+      best = c->item_frames;
+    }
+  }
+  c->item_frames = best;
+  if (std::getenv("RENE_DEBUG")) std::fprintf(stderr, "[rene] tuned: %u frames per work item (0 = whole launch) for launches of %u frames\n", best, n_frames);
+  return rene_reset(c);
 }
 
 int rene_framebuffer(rene_ctx* c, void** device_ptr, size_t* n_floats) {

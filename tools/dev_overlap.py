@@ -16,6 +16,8 @@ for nm in names:
     for flags in (0, abi.FLAG_OVERLAP):
         with api.Renderer(s, flags=flags) as r:
             r.render(0, 4); r.sync(); r.reset()
+            if os.environ.get("RENE_DEV_TUNE") == "1":
+                r.tune(F)
             t0 = time.perf_counter()
             for k in range(6):
                 r.render(k * F, F)

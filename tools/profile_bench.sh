@@ -9,7 +9,7 @@ set -e
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 TAG=${1:-r01}
-STEPS=${2:-16}
+STEPS=${2:-4}
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $OUT/prof_${TAG}_stats -o stats -- python3 $R/bench.py --steps $STEPS --warmup 1 --no-cpu-baseline > $OUT/prof_${TAG}_stats.log 2>&1
 echo "stats pass done"

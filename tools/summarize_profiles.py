@@ -30,8 +30,8 @@ def q(path, sql):
 
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-    frames_per_step = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-    cmd = sys.argv[3] if len(sys.argv) > 3 else "python3 bench.py --steps 16 --warmup 1 --no-cpu-baseline"
+    frames_per_step = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+    cmd = sys.argv[3] if len(sys.argv) > 3 else "python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline"
     g = os.path.join(ROOT, "gpurun_out")
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
