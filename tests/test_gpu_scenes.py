@@ -189,3 +189,38 @@ def test_overlapping_launches_are_bit_identical(name):
     for k in ("rays_closest", "rays_shadow", "rays_emitter", "paths", "hits", "adds", "launches", "frames"):
         assert sa[k] == sb[k], k
     assert np.isfinite(a[0]).all() and a[0].sum() > 0
+
+
+@pytest.mark.parametrize("name", ["cornell", "dragon", "fog"])
+def test_every_work_item_cut_and_rene_tune_give_the_same_bits(name, monkeypatch):
+    """A launch cuts each pixel's frames into n work items that hand the running sums on (item_publish /
+    item_ready); the order of additions does not depend on n, so neither does any bit of the three layers.
+    rene_tune measures which n is fastest, resets the context and leaves nothing else behind."""
+    s = {"cornell": lambda: scenes.cornell_box(96, 96), "dragon": lambda: scenes.dragon_class(96, 54, 24, 26),
+         "fog": lambda: scenes.cornell_fog(64, 64)}[name]()
+    with api.Renderer(s, flags=abi.FLAG_SINGLE_LEVEL | abi.FLAG_COUNTERS) as r:
+        r.render(0, 13)
+        r.render(13, 7)
+        want = [r.download(k) for k in range(3)]
+        st = r.stats().as_dict()
+    for levels in ("1", "2", "3", "5", "13", "31"):  # 13 frames: uneven cuts, one frame per item, more levels than frames
+        monkeypatch.setenv("RENE_LEVELS", levels)
+        with api.Renderer(s, flags=abi.FLAG_COUNTERS) as r:
+            r.render(0, 13)
+            r.render(13, 7)
+            for k in range(3):
+                np.testing.assert_array_equal(r.download(k), want[k], err_msg=f"levels {levels} layer {k}")
+            got = r.stats().as_dict()
+            assert {k: got[k] for k in ("paths", "rays_closest", "rays_shadow", "rays_emitter", "adds")} == \
+                   {k: st[k] for k in ("paths", "rays_closest", "rays_shadow", "rays_emitter", "adds")}
+    monkeypatch.delenv("RENE_LEVELS")
+    for flags in (0, abi.FLAG_OVERLAP):
+        with api.Renderer(s, flags=flags) as r:
+            r.render(0, 3)  # something to be discarded
+            r.tune(13)
+            z = r.stats().as_dict()
+            assert z["frames"] == 0 and z["launches"] == 0 and not r.download(0).any()
+            r.render(0, 13)
+            r.render(13, 7)
+            for k in range(3):
+                np.testing.assert_array_equal(r.download(k), want[k])
