@@ -209,7 +209,9 @@ typedef struct rene_opts {
   uint32_t shard_rank;   /* this context renders tiles (or frames) with index % shard_count == shard_rank */
   uint32_t shard_count;  /* 0 or 1 = unsharded */
   uint32_t reserved;
-  void* framebuffer;     /* optional caller-owned DEVICE buffer of 3*yres*xres*4 floats, else NULL */
+  void* framebuffer;     /* optional caller-owned DEVICE buffer of 3*yres*xres*4 floats (zeroed), else NULL.  The fourth
+                            float of every pixel belongs to the device (the version of the work item that committed the
+                            sums); read r, g, b only, and zero the image through rene_reset */
   void* stream;          /* optional hipStream_t to launch on, else NULL (library-owned stream) */
 } rene_opts;
 

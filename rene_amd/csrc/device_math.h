@@ -96,6 +96,17 @@ RENE_DEV float pcg_range(Pcg& r, float lo, float hi) { return lo + (hi - lo) * p
 
 // x % n: a 32-bit remainder is ~20 VALU instructions on CDNA; n is 1 or a small power of two in
 // most scenes (lobe count, emitter count, triangles of a quad emitter), which is a single AND
+// x / n for x < 2^31 and a quotient below 2^22, through the reciprocal the host supplies (inv = 1.0f / n): the float
+// estimate is off by at most one, the remainder says which way.  Replaces the ~24-instruction expansion of an
+// integer division in the work-item bookkeeping.
+RENE_DEV uint32_t udiv_small(uint32_t x, uint32_t n, float inv, uint32_t& rem) {
+  uint32_t q = (uint32_t)((float)x * inv);
+  int32_t r = (int32_t)(x - q * n);
+  if (r < 0) { q--; r += (int32_t)n; }
+  if (r >= (int32_t)n) { q++; r -= (int32_t)n; }
+  rem = (uint32_t)r;
+  return q;
+}
 RENE_DEV uint32_t umod(uint32_t x, uint32_t n) { return (n & (n - 1u)) == 0u ? (x & (n - 1u)) : (x % n); }
 
 // sin/cos of 2*pi*x for x in [0,1): v_sin_f32 / v_cos_f32 take their argument in revolutions

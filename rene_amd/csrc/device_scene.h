@@ -208,7 +208,7 @@ enum : uint32_t {
 };
 
 struct RenderParams {
-  float* framebuffer;      // [3][H][W][4]
+  float* framebuffer;      // [3][H][W][4]: r, g, b sums + the record's version (device_code.inc, fb_store)
   const uint32_t* seeds;   // n_frames frame seeds
   uint32_t* work_counter;  // next work id
   unsigned long long* counters;  // 9 x u64
@@ -218,18 +218,19 @@ struct RenderParams {
   uint32_t tiles_x, n_tiles;
   uint32_t flags;
   uint32_t n_levels;       // every pixel's frames are cut into n_levels work items of level_step frames (ordered hand-off)
-  uint32_t epoch;          // launch number (1 .. 2^27 - 1)
-  uint32_t* item_done;     // [n_work] per-pixel hand-off flags: epoch << 5 | items of the pixel committed so far (item_publish)
+  uint32_t epoch;          // launch number (1 .. 2^27 - 1); a pixel record's version is epoch << 5 | items committed
+  uint32_t* item_done;     // [n_work] the same versions for the traversal-restart kernels, whose records are 12 bytes
   uint32_t ready_min;      // traversal-restart kernel: lanes waiting before the logic step runs
   uint32_t leaf_min;       // traversal-restart kernel: lanes at a leaf before the leaf step runs
   uint32_t level_step;     // frames per work item: item (level, pixel) renders frames [level * step, min(F, (level + 1) * step))
   uint32_t static_waves;   // waves whose first batch is assigned statically (<= co-resident waves)
   uint32_t work_batch;     // work ids a wave takes per global atomic: 128 when items are plentiful, fewer
                            // (down to 16) when a launch has too few items to give every wave a full batch
-  uint32_t prev_final;     // item_done[] value the context's previous launch leaves behind (0: none): what a pixel's
-                           // first item waits for
+  uint32_t prev_final;     // version the context's previous launch leaves on every pixel record (0: a zeroed image):
+                           // what a pixel's first item waits for
   uint32_t* resident;      // RENE_FLAG_OVERLAP: host-visible [waves]; every wave stores `epoch` here when it starts, so the
                            // host can tell that the whole launch is resident before it submits the next one (else null)
+  float inv_n_work, inv_tiles_x;  // 1.0f / n_work, 1.0f / tiles_x (udiv_small in the work-item bookkeeping)
 };
 
 }  // namespace rene

@@ -66,7 +66,7 @@ struct rene_ctx {
   bool own_stream = false;
   // RENE_FLAG_OVERLAP: consecutive launches alternate between `stream` and `stream2`, so that a launch starts
   // filling the chip while the previous one drains its longest paths (its own work counter each; the kernels
-  // order the two launches' updates of a pixel through item_done[], device_code.inc item_publish / item_ready)
+  // order the two launches' updates of a pixel through the version its records carry, device_code.inc item_load)
   hipStream_t stream2 = nullptr;
   hipEvent_t join_event = nullptr;
   uint32_t* d_work_counter2 = nullptr;
@@ -81,9 +81,9 @@ struct rene_ctx {
   bool own_fb = false;
   size_t fb_floats = 0;
   uint32_t* d_work_counter = nullptr;
-  uint32_t* d_item_done = nullptr;
   uint32_t epoch = 0, prev_final = 0;
   uint32_t item_frames = 0;  // frames per work item; 0 = one item per pixel and launch (rene_tune picks)
+  uint32_t* d_item_done = nullptr;  // [n_work] versions, traversal-restart kernels only (device_code.inc, item_flag_publish)
   unsigned long long* d_counters = nullptr;
   // stage-separated wavefront integrator (BVH scenes): path state in HBM + a pinned word for the host loop
   bool wavefront = false;
@@ -468,6 +468,7 @@ int rene_render(rene_ctx* c, uint32_t first_frame, uint32_t n_frames) {
   P.framebuffer = c->fb;
   P.seeds = pend.d_seeds;
   P.work_counter = work_counter;
+  P.item_done = c->d_item_done;
   P.resident = c->h_resident;  // host-coherent memory: the same pointer is valid on the device
   P.counters = c->d_counters;
   P.n_frames = (uint32_t)seeds.size();
@@ -475,6 +476,8 @@ int rene_render(rene_ctx* c, uint32_t first_frame, uint32_t n_frames) {
   P.shard_rank = c->opts.shard_mode == RENE_SHARD_TILES ? c->opts.shard_rank : 0;
   P.shard_count = c->opts.shard_mode == RENE_SHARD_TILES ? c->opts.shard_count : 1;
   P.tiles_x = c->tiles_x;
+  P.inv_n_work = 1.0f / (float)std::max(1u, c->n_work);
+  P.inv_tiles_x = 1.0f / (float)std::max(1u, c->tiles_x);
   P.n_tiles = c->n_tiles;
   P.flags = c->opts.flags;
   if (c->overlap()) P.flags |= RENE_FLAG_DYNAMIC_FIRST;  // no work item may belong to a wave that is not resident yet
@@ -486,14 +489,14 @@ int rene_render(rene_ctx* c, uint32_t first_frame, uint32_t n_frames) {
   P.level_step = (P.n_frames + levels - 1) / levels;
   P.n_levels = (P.n_frames + P.level_step - 1) / P.level_step;
   P.prev_final = c->prev_final;
-  if (c->epoch >= (1u << 27) - 1u) {  // (drained above) the flag array never needs clearing unless the epoch wraps
+  if (c->epoch >= (1u << 27) - 1u) {  // (drained above) the epoch wraps: every pixel record back to version 0
+    hipMemset2DAsync(c->fb + 3, 4 * sizeof(float), 0, sizeof(float), c->fb_floats / 4, stream);
     hipMemsetAsync(c->d_item_done, 0, std::max<size_t>(1, c->n_work) * sizeof(uint32_t), stream);
     c->epoch = 0;
     P.prev_final = 0;
   }
   P.epoch = ++c->epoch;
   c->prev_final = (P.epoch << 5) | P.n_levels;
-  P.item_done = c->d_item_done;
   // swept with the BVH4 (tools/dev_sweep4.py): dragon-class (Matte) peaks at 24 / 12 (4.96 Grays/s; 20 / 16 gave 4.6);
   // teapot-class, whose logic step is the general-BSDF one, keeps gaining up to ~44 waiting lanes (5.3 vs 4.7)
   P.ready_min = (c->cfg.features & rene::FEAT_GENERAL_BSDF) ? 40 : 24;
@@ -567,7 +570,9 @@ int rene_reset(rene_ctx* c) {
   if (rc != RENE_OK) return rc;
   HIP_TRY(hipMemsetAsync(c->fb, 0, c->fb_floats * sizeof(float), c->stream));
   HIP_TRY(hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream));
+  HIP_TRY(hipMemsetAsync(c->d_item_done, 0, std::max<size_t>(1, c->n_work) * sizeof(uint32_t), c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  c->prev_final = 0;  // the pixel records carry version 0 again
   c->frames = 0;
   c->launches = 0;
   c->kernel_ms = 0.0;
@@ -627,6 +632,7 @@ int rene_download(rene_ctx* c, int layer, int channels, float* dst, size_t dst_f
   const float* src = c->fb + (size_t)layer * n * 4;
   if (channels == 4) {
     HIP_TRY(hipMemcpy(dst, src, n * 4 * sizeof(float), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) dst[4 * i + 3] = 0.0f;  // the device keeps a record's version there; rene's alpha stays 0 (lib.rs:170)
     return RENE_OK;
   }
   std::vector<float> tmp(n * 4);
