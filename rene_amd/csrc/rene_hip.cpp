@@ -82,7 +82,12 @@ struct rene_ctx {
   size_t fb_floats = 0;
   uint32_t* d_work_counter = nullptr;
   uint32_t epoch = 0, prev_final = 0;
-  uint32_t item_frames = 0;  // frames per work item; 0 = one item per pixel and launch (rene_tune picks)
+  // frames per work item: kWholeLaunch = one item per pixel and launch; 0 = not tuned (rene_tune picks): four items per
+  // pixel for the item-loop kernels, whose item switches cost one memory round trip, eight for the BVH kernels, where
+  // untuned scenes have more to lose from unbalanced pixels (dragon-class 6.0 -> 7.9 Grays/s) than from the
+  // bookkeeping (teapot-class 6.8 -> 6.7)
+  static constexpr uint32_t kWholeLaunch = 0xffffffffu;
+  uint32_t item_frames = 0;
   uint32_t* d_item_done = nullptr;  // [n_work] versions, traversal-restart kernels only (device_code.inc, item_flag_publish)
   unsigned long long* d_counters = nullptr;
   // stage-separated wavefront integrator (BVH scenes): path state in HBM + a pinned word for the host loop
@@ -482,7 +487,9 @@ int rene_render(rene_ctx* c, uint32_t first_frame, uint32_t n_frames) {
   P.flags = c->opts.flags;
   if (c->overlap()) P.flags |= RENE_FLAG_DYNAMIC_FIRST;  // no work item may belong to a wave that is not resident yet
   // every pixel's frames in `levels` work items of `step` frames (device_code.inc, render_kernel)
-  uint32_t levels = c->item_frames ? std::min(31u, (P.n_frames + c->item_frames - 1) / c->item_frames) : 1u;
+  uint32_t levels = (c->cfg.features & rene::FEAT_SMALL) ? 4u : 8u;
+  if (c->item_frames == rene_ctx::kWholeLaunch) levels = 1;
+  else if (c->item_frames) levels = std::min(31u, (P.n_frames + c->item_frames - 1) / c->item_frames);
   if (const char* e = std::getenv("RENE_LEVELS")) levels = (uint32_t)std::max(1, std::min(31, std::atoi(e)));  // tuning knob
   if ((c->opts.flags & RENE_FLAG_SINGLE_LEVEL) || P.n_frames < 4) levels = 1;
   levels = std::min(levels, P.n_frames);
@@ -590,7 +597,7 @@ int rene_tune(rene_ctx* c, uint32_t n_frames) {
   uint32_t best = saved;
   double best_ms = 0.0;
   for (uint32_t levels = 1; levels <= 16 && levels <= n_frames; levels *= 2) {
-    c->item_frames = levels == 1 ? 0u : (n_frames + levels - 1) / levels;
+    c->item_frames = levels == 1 ? rene_ctx::kWholeLaunch : (n_frames + levels - 1) / levels;
     const auto t0 = std::chrono::steady_clock::now();
     for (int k = 0; k < 4 && rc == RENE_OK; ++k) rc = rene_render(c, 0, n_frames);  // what is rendered does not matter
     if (rc == RENE_OK) rc = c->drain();
@@ -605,7 +612,8 @@ int rene_tune(rene_ctx* c, uint32_t n_frames) {
     }
   }
   c->item_frames = best;
-  if (std::getenv("RENE_DEBUG")) std::fprintf(stderr, "[rene] tuned: %u frames per work item (0 = whole launch) for launches of %u frames\n", best, n_frames);
+  if (std::getenv("RENE_DEBUG"))
+    std::fprintf(stderr, "[rene] tuned: %u frames per work item for launches of %u frames\n", best == rene_ctx::kWholeLaunch ? n_frames : best, n_frames);
   return rene_reset(c);
 }
 
