@@ -212,3 +212,54 @@ def test_long_short_work_items_are_bit_identical_to_one_item_per_pixel(res, fram
         sa, sb = a.stats().as_dict(), b.stats().as_dict()
         for k in ("rays_closest", "rays_emitter", "paths", "hits", "adds"):
             assert sa[k] == sb[k], k
+
+
+def test_overlap_with_shards_resets_and_a_caller_owned_image():
+    """RENE_FLAG_OVERLAP next to the other ways a context is driven: tile and frame shards, a reset between
+    batches of launches, an image the caller owns (opts.framebuffer: the versions live in its fourth floats),
+    counters.  Everything equals the one-launch-at-a-time result bit for bit."""
+    import torch
+    s = scenes.cornell_box(160, 96)  # ragged against the 32x32 tiles
+    plan = [(0, 9), (9, 4), (13, 1), (14, 10)]
+    with api.Renderer(s, flags=abi.FLAG_COUNTERS) as r:
+        for f0, n in plan:
+            r.render(f0, n)
+        whole = [r.download(l) for l in range(3)]
+        st = r.stats().as_dict()
+    ov = abi.FLAG_OVERLAP | abi.FLAG_COUNTERS
+    for mode in (abi.SHARD_TILES, abi.SHARD_FRAMES):
+        acc = [np.zeros_like(whole[0]) for _ in range(3)]
+        paths = 0
+        for rank in range(3):
+            with api.Renderer(s, flags=ov, shard_mode=mode, shard_rank=rank, shard_count=3) as r:
+                for f0, n in plan:
+                    r.render(f0, n)
+                for l in range(3):
+                    acc[l] += r.download(l)
+                paths += r.stats().paths
+        assert paths == st["paths"]
+        for l in range(3):
+            if mode == abi.SHARD_TILES:
+                assert np.array_equal(acc[l], whole[l])
+            else:
+                np.testing.assert_allclose(acc[l], whole[l], rtol=1e-5, atol=1e-5)
+    fb = torch.zeros((3, 96, 160, 4), dtype=torch.float32, device="cuda:0")
+    with api.Renderer(s, flags=ov, framebuffer_ptr=fb.data_ptr()) as r:
+        r.render(0, 7); r.render(7, 7)      # discarded
+        r.reset()
+        for f0, n in plan:
+            r.render(f0, n)
+        r.sync()
+        got = fb.cpu().numpy()
+        for l in range(3):
+            assert np.array_equal(got[l, :, :, :3], whole[l])
+            assert np.array_equal(r.download(l), whole[l])
+        assert r.download(0, 4)[..., 3].max() == 0.0 and got[0, :, :, 3].view(np.uint32).min() > 0  # versions stay on the device
+        assert {k: v for k, v in r.stats().as_dict().items() if k in ("paths", "rays_closest", "rays_emitter", "adds")} == \
+               {k: v for k, v in st.items() if k in ("paths", "rays_closest", "rays_emitter", "adds")}
+        r.reset()
+        assert not fb.any()
+        r.render(0, 9)
+        with api.Renderer(s) as q:
+            q.render(0, 9)
+            assert np.array_equal(r.download(0), q.download(0))
