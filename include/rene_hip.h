@@ -192,7 +192,8 @@ enum {
   RENE_FLAG_FORCE_BVH = 1u << 2, /* traverse the BVH even when the scene qualifies for the small-scene item loop */
   RENE_FLAG_SINGLE_LEVEL = 1u << 3, /* one work item per pixel per launch (no long/short split; same results, for A/B tests) */
   RENE_FLAG_NO_RESTART = 1u << 4, /* BVH scenes: use the plain while-while kernel instead of the traversal-restart one (A/B tests) */
-  RENE_FLAG_DYNAMIC_FIRST = 1u << 5, /* every work batch, the first included, comes from the atomic counter (A/B tests) */
+  RENE_FLAG_DYNAMIC_FIRST = 1u << 5, /* accepted and ignored: every work batch comes from the atomic counter (a statically owned
+                                        first batch made a launch depend on all of its waves being resident) */
   RENE_FLAG_WAVEFRONT = 1u << 6, /* BVH scenes: the stage-separated wavefront integrator (wavefront.inc) instead of the traversal-restart megakernel */
   RENE_FLAG_OVERLAP = 1u << 7 /* consecutive rene_render launches alternate between two streams so that one starts while the
                                  previous drains its longest paths; per-pixel ordering is kept on the device (bit-identical

@@ -485,7 +485,13 @@ int rene_render(rene_ctx* c, uint32_t first_frame, uint32_t n_frames) {
   P.inv_tiles_x = 1.0f / (float)std::max(1u, c->tiles_x);
   P.n_tiles = c->n_tiles;
   P.flags = c->opts.flags;
-  if (c->overlap()) P.flags |= RENE_FLAG_DYNAMIC_FIRST;  // no work item may belong to a wave that is not resident yet
+  // No work item may belong to a wave that is not resident: items wait for their predecessors, and a statically owned
+  // first batch of a wave that has not been given a slot -- the device shared with another process, or the previous
+  // launch still draining -- can be waited for by every wave that has one (seen: two processes' counting launches on
+  // one GPU, each holding the slots the other's missing waves needed).  With every batch taken from the atomic
+  // counter the item a lane waits for is always in the hands of a resident lane.  (The static first batch saved
+  // 0.05 ms per launch.)
+  P.flags |= RENE_FLAG_DYNAMIC_FIRST;
   // every pixel's frames in `levels` work items of `step` frames (device_code.inc, render_kernel)
   uint32_t levels = (c->cfg.features & rene::FEAT_SMALL) ? 4u : 8u;
   if (c->item_frames == rene_ctx::kWholeLaunch) levels = 1;
