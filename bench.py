@@ -152,7 +152,7 @@ def main():
     bytes_per_ray = abi.algorithmic_bytes(cst) / max(1, cst.rays)
 
     # ---- untimed: work-item granularity for launches of F frames (rene_tune; no bit of the image depends on it) ----
-    r.tune(F)
+    r.tune(max(nf for _, nf in launches))
 
     # ---- warmup (kernel + the collective: RCCL sets its rings up lazily), then a clean image ----
     for k in range(Wm):
