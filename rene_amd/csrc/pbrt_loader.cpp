@@ -779,8 +779,8 @@ struct Builder {
   // ---- LDR images: load_image's fall-through branch (intermediate_scene.rs:657-675) decodes with the
   // `image` crate (0.24.1, absent from /root/reference) and stores, per pixel of DynamicImage::pixels()
   // (RGBA8), inverse_gamma_correct(c / 255) for r, g, b (intermediate_scene.rs:616-622) and a / 255.
-  // Restated here for PNG (RFC 2083: zlib stream + the five scanline filters), 8 bits per sample, not
-  // interlaced; grey -> r = g = b, missing alpha -> 255, like the crate's to-RGBA8 conversion.
+  // Restated here for PNG (RFC 2083: zlib stream + the five scanline filters, Adam7 interlacing, 1 to 16 bits per
+  // sample, tRNS); grey -> r = g = b, missing alpha -> 255, like the crate's to-RGBA8 conversion.
   static float inverse_gamma_correct(float v) {
     return v <= 0.04045f ? v / 12.92f : std::pow((v + 0.055f) / 1.055f, 2.4f);
   }
@@ -813,67 +813,96 @@ struct Builder {
       p += 12 + (size_t)len;
     }
     if (!w || !h || idat.empty()) bad("no image data");
-    const bool packed = depth < 8 && (depth == 1 || depth == 2 || depth == 4) && (ctype == 0 || ctype == 3);
-    if (depth != 8 && !packed) unsupported("PNG with " + std::to_string(depth) + " bits per sample (" + file + ")");
-    if (interlace) unsupported("interlaced PNG (" + file + ")");
     uint32_t ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     if (!ch) bad("colour type");
+    const bool depth_ok = depth == 8 || (depth == 16 && ctype != 3) || ((depth == 1 || depth == 2 || depth == 4) && (ctype == 0 || ctype == 3));
+    if (!depth_ok) bad("bit depth");
+    if (interlace > 1) bad("interlace method");
     if ((uint64_t)w * h > (1ull << 28)) bad("too large");
-    const size_t stride = ((size_t)w * ch * depth + 7) / 8;  // bytes per scanline
+    // one pass, or the seven of Adam7 (RFC 2083 section 2.6): first pixel and step of each reduced image
+    static const uint32_t ax0[7] = {0, 4, 0, 2, 0, 1, 0}, ay0[7] = {0, 0, 4, 0, 2, 0, 1}, adx[7] = {8, 8, 4, 4, 2, 2, 1}, ady[7] = {8, 8, 8, 4, 4, 2, 2};
+    struct Pass { uint32_t x0, y0, dx, dy, pw, ph; size_t stride; };
+    std::vector<Pass> passes;
+    size_t raw_bytes = 0;
+    for (int k = 0; k < (interlace ? 7 : 1); ++k) {
+      Pass q{interlace ? ax0[k] : 0u, interlace ? ay0[k] : 0u, interlace ? adx[k] : 1u, interlace ? ady[k] : 1u, 0, 0, 0};
+      q.pw = w > q.x0 ? (w - q.x0 + q.dx - 1) / q.dx : 0;
+      q.ph = h > q.y0 ? (h - q.y0 + q.dy - 1) / q.dy : 0;
+      if (!q.pw || !q.ph) continue;
+      q.stride = ((size_t)q.pw * ch * depth + 7) / 8;  // bytes per scanline of the pass
+      raw_bytes += (q.stride + 1) * q.ph;
+      passes.push_back(q);
+    }
     const size_t bpp = std::max<size_t>(1, (size_t)ch * depth / 8);  // filter distance, RFC 2083 section 6.2
-    std::vector<unsigned char> raw((stride + 1) * h);
+    std::vector<unsigned char> raw(raw_bytes);
     uLongf out_len = (uLongf)raw.size();
     if (uncompress(raw.data(), &out_len, reinterpret_cast<const Bytef*>(idat.data()), (uLong)idat.size()) != Z_OK ||
         out_len != raw.size())
       bad("zlib stream");
-    std::vector<unsigned char> px(stride * h);
-    for (uint32_t y = 0; y < h; ++y) {  // un-filter, RFC 2083 section 6
-      const unsigned char* in = raw.data() + (stride + 1) * y;
-      unsigned char* cur = px.data() + stride * y;
-      const unsigned char* up = y ? cur - stride : nullptr;
-      const unsigned filter = in[0];
-      if (filter > 4) bad("filter type");
-      for (size_t i = 0; i < stride; ++i) {
-        int a = i >= bpp ? cur[i - bpp] : 0, b = up ? up[i] : 0, c = (up && i >= bpp) ? up[i - bpp] : 0, pred = 0;
-        switch (filter) {
-          case 1: pred = a; break;
-          case 2: pred = b; break;
-          case 3: pred = (a + b) / 2; break;
-          case 4: {
-            int pa = std::abs(b - c), pb = std::abs(a - c), pc = std::abs(a + b - 2 * c);
-            pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
-            break;
+    // samples at their original depth, one uint16 per channel, in image order
+    std::vector<uint16_t> smp((size_t)w * h * ch);
+    size_t at = 0;
+    std::vector<unsigned char> line, prev;
+    for (const Pass& q : passes) {
+      line.assign(q.stride, 0);
+      prev.assign(q.stride, 0);
+      for (uint32_t py = 0; py < q.ph; ++py) {  // un-filter, RFC 2083 section 6
+        const unsigned char* in = raw.data() + at;
+        at += q.stride + 1;
+        const unsigned filter = in[0];
+        if (filter > 4) bad("filter type");
+        for (size_t i = 0; i < q.stride; ++i) {
+          int a = i >= bpp ? line[i - bpp] : 0, b = py ? prev[i] : 0, c = (py && i >= bpp) ? prev[i - bpp] : 0, pred = 0;
+          switch (filter) {
+            case 1: pred = a; break;
+            case 2: pred = b; break;
+            case 3: pred = (a + b) / 2; break;
+            case 4: {
+              int pa = std::abs(b - c), pb = std::abs(a - c), pc = std::abs(a + b - 2 * c);
+              pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+              break;
+            }
+            default: break;
           }
-          default: break;
+          line[i] = (unsigned char)(in[1 + i] + pred);
         }
-        cur[i] = (unsigned char)(in[1 + i] + pred);
+        const uint32_t y = q.y0 + py * q.dy;
+        for (uint32_t pxi = 0; pxi < q.pw; ++pxi) {
+          uint16_t* o = &smp[((size_t)y * w + q.x0 + (size_t)pxi * q.dx) * ch];
+          for (uint32_t c2 = 0; c2 < ch; ++c2) {
+            const size_t k = (size_t)pxi * ch + c2;
+            if (depth == 8) o[c2] = line[k];
+            else if (depth == 16) o[c2] = (uint16_t)((line[2 * k] << 8) | line[2 * k + 1]);
+            else {  // 1 / 2 / 4-bit samples, most significant first
+              const size_t bit = k * depth;
+              o[c2] = (line[bit / 8] >> (8 - depth - bit % 8)) & ((1u << depth) - 1u);
+            }
+          }
+        }
+        prev.swap(line);
       }
     }
+    // to RGBA8 like the crate's DynamicImage::to_rgba8: grey levels scale to 0..255, 16-bit samples round to
+    // (v + 128) / 257, a tRNS colour key (grey / RGB images) makes the matching pixels transparent
+    const unsigned maxv = (1u << depth) - 1u;
+    auto to8 = [&](unsigned v) -> unsigned { return depth == 16 ? (v + 128u) / 257u : depth == 8 ? v : v * 255u / maxv; };
+    auto be16 = [&](size_t k) -> unsigned { return k + 1 < trns.size() ? (unsigned)((trns[k] << 8) | trns[k + 1]) : 0x10000u; };
     std::vector<float> rgba((size_t)w * h * 4);
-    if (packed) {  // 1 / 2 / 4-bit samples, most significant first; grey levels scale to 0..255
-      std::vector<unsigned char> wide((size_t)w * h);
-      const unsigned maxv = (1u << depth) - 1u;
-      for (uint32_t y = 0; y < h; ++y)
-        for (uint32_t x = 0; x < w; ++x) {
-          const size_t bit = (size_t)x * depth;
-          unsigned v = (px[stride * y + bit / 8] >> (8 - depth - bit % 8)) & maxv;
-          wide[(size_t)y * w + x] = (unsigned char)(ctype == 0 ? v * 255u / maxv : v);
-        }
-      px.swap(wide);
-    }
     for (size_t i = 0; i < (size_t)w * h; ++i) {
-      const unsigned char* s = px.data() + i * ch;
+      const uint16_t* s = &smp[i * ch];
       unsigned r, g, b, a = 255;
       if (ctype == 3) {
         if ((size_t)s[0] * 3 + 2 >= plte.size()) bad("palette index");
         r = plte[s[0] * 3]; g = plte[s[0] * 3 + 1]; b = plte[s[0] * 3 + 2];
         if (s[0] < trns.size()) a = trns[s[0]];
       } else if (ch <= 2) {
-        r = g = b = s[0];
-        if (ch == 2) a = s[1];
+        r = g = b = to8(s[0]);
+        if (ch == 2) a = to8(s[1]);
+        else if (trns.size() >= 2 && s[0] == be16(0)) a = 0;
       } else {
-        r = s[0]; g = s[1]; b = s[2];
-        if (ch == 4) a = s[3];
+        r = to8(s[0]); g = to8(s[1]); b = to8(s[2]);
+        if (ch == 4) a = to8(s[3]);
+        else if (trns.size() >= 6 && s[0] == be16(0) && s[1] == be16(2) && s[2] == be16(4)) a = 0;
       }
       rgba[i * 4 + 0] = inverse_gamma_correct((float)r / 255.0f);
       rgba[i * 4 + 1] = inverse_gamma_correct((float)g / 255.0f);

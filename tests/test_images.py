@@ -290,3 +290,94 @@ def test_tga_and_bmp_written_by_pil(tmp_path, hip_lib):
         im.save(tmp_path / name, **kw)
         want = np.asarray(Image.open(tmp_path / name).convert("RGBA"), dtype=np.uint8)
         np.testing.assert_allclose(load(tmp_path, name), expect_ldr(want), rtol=5e-7, atol=0, err_msg=name)
+
+
+# ------------------------------------------------------------------------------------------------ PNG, the rest of RFC 2083
+def png_bytes(smp, depth, ctype, interlace=False, plte=None, trns=None, filters=(0, 1, 2, 3, 4)):
+    """smp: [h, w, channels] integer samples at `depth` bits.  Rows are filtered with the types in `filters` in turn."""
+    h, w, ch = smp.shape
+
+    def chunk(t, body):
+        return struct.pack(">I", len(body)) + t + body + struct.pack(">I", zlib.crc32(t + body) & 0xffffffff)
+
+    def scanlines(sub):
+        out, prev = b"", None
+        sh, sw, _ = sub.shape
+        bpp = max(1, ch * depth // 8)
+        for y in range(sh):
+            row = sub[y].reshape(-1)
+            if depth == 16:
+                line = np.stack([row >> 8, row & 255], axis=1).reshape(-1).astype(np.uint8)
+            elif depth == 8:
+                line = row.astype(np.uint8)
+            else:
+                bits = np.zeros(((len(row) * depth + 7) // 8) * 8, np.uint8)
+                for k, v in enumerate(row):
+                    for b in range(depth):
+                        bits[k * depth + b] = (int(v) >> (depth - 1 - b)) & 1
+                line = np.packbits(bits)
+            f = filters[y % len(filters)]
+            cur = line.astype(np.int32)
+            a = np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]]) if len(cur) > bpp else np.zeros_like(cur)
+            b = prev.astype(np.int32) if prev is not None else np.zeros_like(cur)
+            c = np.concatenate([np.zeros(bpp, np.int32), b[:-bpp]]) if len(cur) > bpp else np.zeros_like(cur)
+            if f == 0: pred = np.zeros_like(cur)
+            elif f == 1: pred = a
+            elif f == 2: pred = b
+            elif f == 3: pred = (a + b) // 2
+            else:
+                pa, pb, pc = np.abs(b - c), np.abs(a - c), np.abs(a + b - 2 * c)
+                pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, b, c))
+            out += bytes([f]) + ((cur - pred) % 256).astype(np.uint8).tobytes()
+            prev = line
+        return out
+
+    if interlace:
+        passes = [(0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)]
+        raw = b"".join(scanlines(smp[y0::dy, x0::dx]) for x0, y0, dx, dy in passes if smp[y0::dy, x0::dx].size)
+    else:
+        raw = scanlines(smp)
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 1 if interlace else 0))
+    if plte is not None:
+        out += chunk(b"PLTE", np.asarray(plte, np.uint8).tobytes())
+    if trns is not None:
+        out += chunk(b"tRNS", trns)
+    return out + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b"")
+
+
+@pytest.mark.parametrize("interlace", [False, True])
+def test_png_every_depth_interlacing_and_colour_keys(tmp_path, hip_lib, interlace):
+    rng = np.random.default_rng(11)
+    h, w = 11, 13  # smaller than some Adam7 passes' strides: empty and ragged passes occur
+    for depth, ctype, ch in ((16, 0, 1), (16, 2, 3), (16, 4, 2), (16, 6, 4), (8, 2, 3), (8, 6, 4), (4, 0, 1), (2, 0, 1), (1, 0, 1), (4, 3, 1), (1, 3, 1)):
+        smp = rng.integers(0, 1 << depth, (h, w, ch))
+        plte = trns = None
+        if ctype == 3:
+            plte = rng.integers(0, 256, (1 << depth, 3))
+            trns = bytes(rng.integers(0, 256, 1 << (depth - 1)).tolist())  # shorter than the palette: the rest is opaque
+        elif ctype == 0 and depth != 2:
+            key = int(smp[3, 4, 0])
+            trns = struct.pack(">H", key)
+        elif ctype == 2:
+            key = smp[5, 6]
+            trns = struct.pack(">HHH", *[int(v) for v in key])
+        (tmp_path / "a.png").write_bytes(png_bytes(smp, depth, ctype, interlace, plte, trns))
+        got = load(tmp_path, "a.png")
+        to8 = (lambda v: (v + 128) // 257) if depth == 16 else (lambda v: v) if depth == 8 else (lambda v: v * 255 // ((1 << depth) - 1))
+        want = np.empty((h, w, 4), np.uint8)
+        if ctype == 3:
+            want[..., :3] = plte[smp[..., 0]]
+            t = np.frombuffer(trns, np.uint8)
+            want[..., 3] = np.where(smp[..., 0] < len(t), t[np.minimum(smp[..., 0], len(t) - 1)], 255)
+        elif ch <= 2:
+            want[..., :3] = to8(smp[..., :1])
+            want[..., 3] = to8(smp[..., 1]) if ch == 2 else (np.where(smp[..., 0] == key, 0, 255) if trns else 255)
+        else:
+            want[..., :3] = to8(smp[..., :3])
+            want[..., 3] = to8(smp[..., 3]) if ch == 4 else np.where((smp == key).all(axis=2), 0, 255)
+        np.testing.assert_allclose(got, expect_ldr(want), rtol=5e-7, atol=0, err_msg=f"depth {depth} colour type {ctype}")
+    # PIL reads what this encoder writes (a check of the encoder, not of the decoder)
+    from PIL import Image
+    smp = rng.integers(0, 256, (h, w, 3))
+    (tmp_path / "p.png").write_bytes(png_bytes(smp, 8, 2, interlace))
+    np.testing.assert_array_equal(np.asarray(Image.open(tmp_path / "p.png")), smp.astype(np.uint8))

@@ -312,9 +312,8 @@ def test_png_image_textures(tmp_path, hip_lib):
         lin = np.where(v <= 0.04045, v / 12.92, ((v + 0.055) / 1.055) ** 2.4)
         np.testing.assert_allclose(got[..., :3], lin[..., :3], rtol=2e-6, atol=1e-7)
         np.testing.assert_array_equal(got[..., 3], v[..., 3])
-    # 16-bit and interlaced files are refused, not mis-decoded; so are other LDR formats
-    Image.fromarray(rgba[..., 0].astype(np.uint16) << 8).save(tmp_path / "deep.png")  # uint16 -> 16-bit grey
-    for name, code in (("deep.png", -4), ("missing.png", -6), ("x.jpg", -4)):
+    # other LDR formats are refused, not guessed (16-bit and interlaced PNG: tests/test_images.py)
+    for name, code in (("missing.png", -6), ("x.jpg", -4)):
         (tmp_path / "bad.pbrt").write_text(f'WorldBegin\nTexture "t" "spectrum" "imagemap" "string filename" "{name}"\nWorldEnd\n')
         with pytest.raises(api.ReneError) as e:
             loader.load_pbrt(str(tmp_path / "bad.pbrt"))
