@@ -13,6 +13,7 @@
 //   * OpenEXR 2 scan-line images ("OpenEXR File Layout", "Technical Introduction to OpenEXR"): HALF / FLOAT /
 //     UINT channels R, G, B, A (or Y) without subsampling; compression NONE, RLE, ZIPS, ZIP and PIZ (Huffman
 //     + Haar wavelet + value table).  Tiled, deep and multi-part files, PXR24, B44 and DWA are refused.
+//   * JPEG: see decode_jpeg at the end of this file.
 // PNG lives in pbrt_loader.cpp.  Parity: unpinned (no reference test reads an image file); tests/test_images.py
 // decodes files written by independent Python encoders and, where /root/reference is present, the
 // reference's own PIZ-compressed EXR renders.
@@ -636,6 +637,434 @@ bool decode_exr(const std::string& data, uint32_t& w, uint32_t& h, std::vector<f
         }
       }
     }
+  }
+  return true;
+}
+
+}  // namespace rene
+
+// ------------------------------------------------------------------------------------------------- JPEG
+// ITU-T T.81 (JPEG), 8-bit Huffman-coded frames: baseline / extended sequential (SOF0, SOF1) and progressive
+// (SOF2: spectral selection + successive approximation), one (grey) or three (YCbCr, or RGB when an Adobe APP14
+// marker says so) components, restart intervals, any sampling factors up to 2 x 2.  The inverse DCT is evaluated in
+// floating point (the transform libjpeg's and the jpeg-decoder crate's fixed-point kernels approximate to within one
+// level); chroma is brought to full resolution with the triangle filters both use for 2:1 horizontal and 2 x 2
+// sampling ("fancy upsampling"), by replication otherwise.  Arithmetic-coded, lossless, 12-bit and four-component
+// files are refused.
+namespace rene {
+
+namespace {
+
+const unsigned char kZigZag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                   41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                   30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+struct Huff {
+  bool present = false;
+  int mincode[17], maxcode[18], valptr[17];
+  unsigned char vals[256];
+};
+
+struct JComp {
+  int id = 0, h = 1, v = 1, tq = 0;
+  int bw = 0, bh = 0;  // blocks per line / column (padded to the MCU grid)
+  int pw = 0, ph = 0;  // sample dimensions of the component (ceil(W * h / hmax))
+  std::vector<int16_t> coef;
+  int pred = 0, td = 0, ta = 0;
+};
+
+struct JBits {
+  const unsigned char* p;
+  size_t n, at;
+  uint32_t acc = 0;
+  int bits = 0;
+  bool hit_marker = false;
+  void fill() {
+    while (bits <= 24) {
+      unsigned c = 0;
+      if (!hit_marker && at < n) {
+        c = p[at];
+        if (c == 0xff) {
+          unsigned d = at + 1 < n ? p[at + 1] : 0xd9u;
+          if (d == 0) at += 2;               // stuffed zero
+          else { hit_marker = true; c = 0; }  // a marker ends the entropy-coded segment: feed zeros
+        } else {
+          at++;
+        }
+      }
+      acc |= c << (24 - bits);
+      bits += 8;
+    }
+  }
+  int get(int k) {
+    if (k == 0) return 0;
+    fill();
+    int v = (int)(acc >> (32 - k));
+    acc <<= k;
+    bits -= k;
+    return v;
+  }
+  int bit() { return get(1); }
+  void reset() { acc = 0; bits = 0; hit_marker = false; }
+};
+
+int jdecode(JBits& b, const Huff& h) {
+  int code = 0;
+  for (int l = 1; l <= 16; ++l) {
+    code = (code << 1) | b.bit();
+    if (h.maxcode[l] >= 0 && code <= h.maxcode[l] && code >= h.mincode[l]) return h.vals[h.valptr[l] + code - h.mincode[l]];
+  }
+  return -1;
+}
+inline int jextend(int v, int s) { return s && v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }
+
+void idct8x8(const float* in, unsigned char* out, int stride) {
+  static float c[8][8];
+  static bool init = false;
+  if (!init) {
+    for (int x = 0; x < 8; ++x)
+      for (int u = 0; u < 8; ++u) c[x][u] = (float)((u == 0 ? std::sqrt(0.125) : 0.5) * std::cos((2 * x + 1) * u * 3.14159265358979323846 / 16.0));
+    init = true;
+  }
+  float tmp[64];
+  for (int y = 0; y < 8; ++y)      // rows: over u
+    for (int x = 0; x < 8; ++x) {
+      float s = 0.0f;
+      for (int u = 0; u < 8; ++u) s += c[x][u] * in[y * 8 + u];
+      tmp[y * 8 + x] = s;
+    }
+  for (int x = 0; x < 8; ++x)
+    for (int y = 0; y < 8; ++y) {
+      float s = 0.0f;
+      for (int v = 0; v < 8; ++v) s += c[y][v] * tmp[v * 8 + x];
+      int q = (int)std::floor(s + 128.5f);
+      out[y * stride + x] = (unsigned char)(q < 0 ? 0 : q > 255 ? 255 : q);
+    }
+}
+
+}  // namespace
+
+bool decode_jpeg(const std::string& data, uint32_t& w, uint32_t& h, std::vector<unsigned char>& rgba, std::string& err) {
+  const unsigned char* p = reinterpret_cast<const unsigned char*>(data.data());
+  const size_t n = data.size();
+  if (n < 4 || p[0] != 0xff || p[1] != 0xd8) { err = "signature"; return false; }
+  uint16_t qt[4][64] = {};
+  bool have_qt[4] = {false, false, false, false};
+  Huff dc[4], ac[4];
+  std::vector<JComp> comp;
+  bool progressive = false, have_frame = false, done = false;
+  int hmax = 1, vmax = 1, restart = 0, adobe_transform = -1;
+  int mcux = 0, mcuy = 0;
+  size_t at = 2;
+  auto be16 = [&](size_t a) { return (unsigned)((p[a] << 8) | p[a + 1]); };
+  while (!done) {
+    while (at < n && p[at] != 0xff) at++;  // garbage between segments is tolerated like the decoders do
+    while (at < n && p[at] == 0xff) at++;
+    if (at >= n) break;
+    const unsigned m = p[at++];
+    if (m == 0xd9) break;
+    if (m == 0x01 || (m >= 0xd0 && m <= 0xd7)) continue;
+    if (at + 2 > n) { err = "truncated segment"; return false; }
+    const size_t len = be16(at);
+    if (len < 2 || at + len > n) { err = "truncated segment"; return false; }
+    const size_t seg = at + 2, seg_end = at + len;
+    if (m == 0xdb) {  // DQT
+      for (size_t a = seg; a < seg_end;) {
+        const int pq = p[a] >> 4, tq = p[a] & 15;
+        a++;
+        if (tq > 3 || a + (pq ? 128 : 64) > seg_end) { err = "quantisation table"; return false; }
+        for (int k = 0; k < 64; ++k) {
+          qt[tq][k] = pq ? (uint16_t)be16(a) : p[a];
+          a += pq ? 2 : 1;
+        }
+        have_qt[tq] = true;
+      }
+    } else if (m == 0xc4) {  // DHT
+      for (size_t a = seg; a < seg_end;) {
+        if (a + 17 > seg_end) { err = "Huffman table"; return false; }
+        const int tc = p[a] >> 4, th = p[a] & 15;
+        if (tc > 1 || th > 3) { err = "Huffman table"; return false; }
+        Huff& t = tc ? ac[th] : dc[th];
+        int counts[17] = {0}, total = 0;
+        for (int l = 1; l <= 16; ++l) total += counts[l] = p[a + l];
+        a += 17;
+        if (total > 256 || a + total > seg_end) { err = "Huffman table"; return false; }
+        std::memcpy(t.vals, p + a, total);
+        a += total;
+        int code = 0, k = 0;
+        for (int l = 1; l <= 16; ++l) {
+          t.valptr[l] = k;
+          t.mincode[l] = code;
+          code += counts[l];
+          k += counts[l];
+          t.maxcode[l] = counts[l] ? code - 1 : -1;
+          code <<= 1;
+        }
+        t.present = true;
+      }
+    } else if (m == 0xc0 || m == 0xc1 || m == 0xc2) {  // SOF
+      if (have_frame) { err = "second frame"; return false; }
+      if (len < 8) { err = "frame header"; return false; }
+      if (p[seg] != 8) { err = std::to_string(p[seg]) + "-bit samples"; return false; }
+      h = be16(seg + 1);
+      w = be16(seg + 3);
+      const int nc = p[seg + 5];
+      if (!w || !h) { err = "empty image"; return false; }
+      if (nc != 1 && nc != 3) { err = std::to_string(nc) + " components"; return false; }
+      if (seg + 6 + 3 * (size_t)nc > seg_end) { err = "frame header"; return false; }
+      comp.resize(nc);
+      for (int c = 0; c < nc; ++c) {
+        comp[c].id = p[seg + 6 + 3 * c];
+        comp[c].h = p[seg + 7 + 3 * c] >> 4;
+        comp[c].v = p[seg + 7 + 3 * c] & 15;
+        comp[c].tq = p[seg + 8 + 3 * c];
+        if (comp[c].h < 1 || comp[c].h > 2 || comp[c].v < 1 || comp[c].v > 2 || comp[c].tq > 3) { err = "sampling factors"; return false; }
+        hmax = std::max(hmax, comp[c].h);
+        vmax = std::max(vmax, comp[c].v);
+      }
+      mcux = ((int)w + 8 * hmax - 1) / (8 * hmax);
+      mcuy = ((int)h + 8 * vmax - 1) / (8 * vmax);
+      for (JComp& c : comp) {
+        c.bw = mcux * c.h;
+        c.bh = mcuy * c.v;
+        c.pw = ((int)w * c.h + hmax - 1) / hmax;
+        c.ph = ((int)h * c.v + vmax - 1) / vmax;
+        c.coef.assign((size_t)c.bw * c.bh * 64, 0);
+      }
+      progressive = m == 0xc2;
+      have_frame = true;
+    } else if (m == 0xc3 || (m >= 0xc5 && m <= 0xcf && m != 0xc8 && m != 0xcc)) {
+      err = "lossless / hierarchical / arithmetic-coded JPEG";
+      return false;
+    } else if (m == 0xdd) {  // DRI
+      restart = (int)be16(seg);
+    } else if (m == 0xee) {  // Adobe
+      if (len >= 14 && std::memcmp(p + seg, "Adobe", 5) == 0) adobe_transform = p[seg + 11];
+    } else if (m == 0xda) {  // SOS + entropy-coded data
+      if (!have_frame) { err = "scan before frame"; return false; }
+      const int ns = p[seg];
+      if (ns < 1 || ns > (int)comp.size() || seg + 1 + 2 * (size_t)ns + 3 > seg_end) { err = "scan header"; return false; }
+      int order[3];
+      for (int k = 0; k < ns; ++k) {
+        int id = p[seg + 1 + 2 * k], ci = -1;
+        for (size_t c = 0; c < comp.size(); ++c)
+          if (comp[c].id == id) ci = (int)c;
+        if (ci < 0) { err = "scan component"; return false; }
+        order[k] = ci;
+        comp[ci].td = p[seg + 2 + 2 * k] >> 4;
+        comp[ci].ta = p[seg + 2 + 2 * k] & 15;
+        if (comp[ci].td > 3 || comp[ci].ta > 3) { err = "scan tables"; return false; }
+      }
+      int Ss = p[seg + 1 + 2 * ns], Se = p[seg + 2 + 2 * ns], Ah = p[seg + 3 + 2 * ns] >> 4, Al = p[seg + 3 + 2 * ns] & 15;
+      if (!progressive) { Ss = 0; Se = 63; Ah = Al = 0; }
+      if (Ss > Se || Se > 63 || (Ss == 0 && Se != 0 && progressive) || (Ss > 0 && ns != 1) || Al > 13) { err = "spectral selection"; return false; }
+      for (int k = 0; k < ns; ++k) {
+        const JComp& c = comp[order[k]];
+        const bool needs_dc = Ss == 0 && Ah == 0;                  // baseline blocks, first DC scans
+        const bool needs_ac = progressive ? Ss > 0 : true;         // baseline blocks, every AC scan
+        if ((needs_dc && !dc[c.td].present) || (needs_ac && !ac[c.ta].present)) {
+          err = "missing Huffman table";
+          return false;
+        }
+      }
+      JBits b{p, n, seg_end};
+      int eobrun = 0, to_restart = restart;
+      for (JComp& c : comp) c.pred = 0;
+      bool bad = false;
+      auto block = [&](JComp& c, int bx, int by) {
+        int16_t* q = &c.coef[((size_t)by * c.bw + bx) * 64];
+        if (!progressive) {
+          int t = jdecode(b, dc[c.td]);
+          if (t < 0 || t > 11) { bad = true; return; }
+          c.pred += jextend(b.get(t), t);
+          q[0] = (int16_t)c.pred;
+          for (int k = 1; k < 64;) {
+            int rs = jdecode(b, ac[c.ta]);
+            if (rs < 0) { bad = true; return; }
+            const int r = rs >> 4, s = rs & 15;
+            if (s == 0) {
+              if (r == 15) { k += 16; continue; }
+              break;
+            }
+            k += r;
+            if (k > 63) { bad = true; return; }
+            q[kZigZag[k]] = (int16_t)jextend(b.get(s), s);
+            k++;
+          }
+        } else if (Ss == 0) {
+          if (Ah == 0) {
+            int t = jdecode(b, dc[c.td]);
+            if (t < 0 || t > 11) { bad = true; return; }
+            c.pred += jextend(b.get(t), t);
+            q[0] = (int16_t)(c.pred * (1 << Al));
+          } else if (b.bit()) {
+            q[0] |= (int16_t)(1 << Al);
+          }
+        } else if (Ah == 0) {
+          if (eobrun > 0) { eobrun--; return; }
+          for (int k = Ss; k <= Se;) {
+            int rs = jdecode(b, ac[c.ta]);
+            if (rs < 0) { bad = true; return; }
+            const int r = rs >> 4, s = rs & 15;
+            if (s == 0) {
+              if (r < 15) {
+                eobrun = (1 << r) - 1 + (r ? b.get(r) : 0);
+                break;
+              }
+              k += 16;
+              continue;
+            }
+            k += r;
+            if (k > Se) { bad = true; return; }
+            q[kZigZag[k]] = (int16_t)(jextend(b.get(s), s) * (1 << Al));
+            k++;
+          }
+        } else {  // AC refinement, T.81 G.1.2.3
+          const int p1 = 1 << Al, m1 = -(1 << Al);
+          int k = Ss;
+          auto refine = [&](int16_t& v) {
+            if (b.bit() && (v & p1) == 0) v = (int16_t)(v >= 0 ? v + p1 : v + m1);
+          };
+          if (eobrun == 0) {
+            for (; k <= Se; ++k) {
+              int rs = jdecode(b, ac[c.ta]);
+              if (rs < 0) { bad = true; return; }
+              int r = rs >> 4, s = rs & 15, value = 0;
+              if (s) {
+                value = b.bit() ? p1 : m1;
+              } else if (r != 15) {
+                eobrun = (1 << r) + (r ? b.get(r) : 0);
+                break;
+              }
+              while (k <= Se) {
+                int16_t& v = q[kZigZag[k]];
+                if (v != 0) refine(v);
+                else if (--r < 0) break;
+                k++;
+              }
+              if (s && k <= Se) q[kZigZag[k]] = (int16_t)value;
+            }
+          }
+          if (eobrun > 0) {
+            for (; k <= Se; ++k) {
+              int16_t& v = q[kZigZag[k]];
+              if (v != 0) refine(v);
+            }
+            eobrun--;
+          }
+        }
+      };
+      auto at_restart = [&]() -> bool {  // true when the data ended
+        if (!restart || --to_restart > 0) return false;
+        // byte-align, swallow the RSTn marker, reset the predictors
+        b.reset();
+        size_t a = b.at;
+        while (a + 1 < n && !(p[a] == 0xff && p[a + 1] >= 0xd0 && p[a + 1] <= 0xd7)) {
+          if (p[a] == 0xff && p[a + 1] != 0 && p[a + 1] != 0xff) return true;  // some other marker: the scan is over
+          a++;
+        }
+        if (a + 1 >= n) return true;
+        b.at = a + 2;
+        for (JComp& c : comp) c.pred = 0;
+        eobrun = 0;
+        to_restart = restart;
+        return false;
+      };
+      if (ns == 1) {
+        JComp& c = comp[order[0]];
+        const int nbx = (c.pw + 7) / 8, nby = (c.ph + 7) / 8;  // a non-interleaved scan covers the component's own blocks
+        bool over = false;
+        for (int by = 0; by < nby && !bad && !over; ++by)
+          for (int bx = 0; bx < nbx && !bad && !over; ++bx) {
+            block(c, bx, by);
+            over = at_restart() && !(by == nby - 1 && bx == nbx - 1);
+          }
+      } else {
+        bool over = false;
+        for (int my = 0; my < mcuy && !bad && !over; ++my)
+          for (int mx = 0; mx < mcux && !bad && !over; ++mx) {
+            for (int k = 0; k < ns && !bad; ++k) {
+              JComp& c = comp[order[k]];
+              for (int v = 0; v < c.v && !bad; ++v)
+                for (int hh = 0; hh < c.h && !bad; ++hh) block(c, mx * c.h + hh, my * c.v + v);
+            }
+            over = at_restart() && !(my == mcuy - 1 && mx == mcux - 1);
+          }
+      }
+      if (bad) { err = "corrupt entropy-coded data"; return false; }
+      // continue after the entropy-coded segment: at the marker that ended it
+      b.reset();
+      at = b.at;
+      while (at + 1 < n && !(p[at] == 0xff && p[at + 1] != 0 && p[at + 1] != 0xff && !(p[at + 1] >= 0xd0 && p[at + 1] <= 0xd7))) at++;
+      continue;
+    }
+    at = seg_end;
+  }
+  if (!have_frame) { err = "no frame"; return false; }
+  // dequantise + inverse DCT into component planes (padded to whole blocks)
+  std::vector<std::vector<unsigned char>> plane(comp.size());
+  for (size_t ci = 0; ci < comp.size(); ++ci) {
+    JComp& c = comp[ci];
+    if (!have_qt[c.tq]) { err = "missing quantisation table"; return false; }
+    const int stride = c.bw * 8;
+    plane[ci].assign((size_t)stride * c.bh * 8, 0);
+    float blk[64];
+    for (int by = 0; by < c.bh; ++by)
+      for (int bx = 0; bx < c.bw; ++bx) {
+        const int16_t* q = &c.coef[((size_t)by * c.bw + bx) * 64];
+        for (int k = 0; k < 64; ++k) blk[kZigZag[k]] = (float)q[kZigZag[k]] * (float)qt[c.tq][k];
+        idct8x8(blk, &plane[ci][(size_t)by * 8 * stride + bx * 8], stride);
+      }
+  }
+  // chroma to full resolution
+  auto sample = [&](size_t ci, int x, int y) -> int {  // clamped fetch inside the component's true extent
+    const JComp& c = comp[ci];
+    x = x < 0 ? 0 : x >= c.pw ? c.pw - 1 : x;
+    y = y < 0 ? 0 : y >= c.ph ? c.ph - 1 : y;
+    return plane[ci][(size_t)y * c.bw * 8 + x];
+  };
+  std::vector<std::vector<unsigned char>> full(comp.size());
+  for (size_t ci = 0; ci < comp.size(); ++ci) {
+    const JComp& c = comp[ci];
+    full[ci].resize((size_t)w * h);
+    const int fx = hmax / c.h, fy = vmax / c.v;
+    for (uint32_t y = 0; y < h; ++y)
+      for (uint32_t x = 0; x < w; ++x) {
+        int v;
+        if (fx == 1 && fy == 1) {
+          v = sample(ci, (int)x, (int)y);
+        } else if (fx == 2 && fy == 1) {  // h2v1 triangle filter: 3/4 nearer, 1/4 farther, alternating rounding
+          const int i = (int)x >> 1;
+          if ((int)x == 0 || (int)x == 2 * c.pw - 1) v = sample(ci, i, (int)y);
+          else v = (x & 1) ? (3 * sample(ci, i, (int)y) + sample(ci, i + 1, (int)y) + 2) >> 2 : (3 * sample(ci, i, (int)y) + sample(ci, i - 1, (int)y) + 1) >> 2;
+        } else if (fx == 2 && fy == 2) {  // h2v2: the same filter in both directions, sixteenths
+          const int i = (int)x >> 1, j = (int)y >> 1, jn = (y & 1) ? j + 1 : j - 1;
+          auto col = [&](int ii) { return 3 * sample(ci, ii, j) + sample(ci, ii, jn); };
+          const int cur = col(i);
+          if ((int)x == 0 || (int)x == 2 * c.pw - 1) v = (4 * cur + 8) >> 4;
+          else v = (x & 1) ? (3 * cur + col(i + 1) + 7) >> 4 : (3 * cur + col(i - 1) + 8) >> 4;
+        } else {
+          v = sample(ci, (int)x / fx, (int)y / fy);
+        }
+        full[ci][(size_t)y * w + x] = (unsigned char)v;
+      }
+  }
+  rgba.resize((size_t)w * h * 4);
+  const bool ycc = comp.size() == 3 && adobe_transform != 0;
+  for (size_t i = 0; i < (size_t)w * h; ++i) {
+    unsigned char* d = &rgba[i * 4];
+    if (comp.size() == 1) {
+      d[0] = d[1] = d[2] = full[0][i];
+    } else if (!ycc) {
+      d[0] = full[0][i]; d[1] = full[1][i]; d[2] = full[2][i];
+    } else {
+      const float Y = full[0][i], cb = (float)full[1][i] - 128.0f, cr = (float)full[2][i] - 128.0f;
+      auto clamp8 = [](float f) { int q = (int)std::floor(f + 0.5f); return (unsigned char)(q < 0 ? 0 : q > 255 ? 255 : q); };
+      d[0] = clamp8(Y + 1.402f * cr);
+      d[1] = clamp8(Y - 0.344136f * cb - 0.714136f * cr);
+      d[2] = clamp8(Y + 1.772f * cb);
+    }
+    d[3] = 255;
   }
   return true;
 }

@@ -12,7 +12,7 @@
 // integrators select volpath (intermediate_scene.rs:1069-1072); Sampler / PixelFilter and all
 // Integrator parameters are ignored (scene.rs:120-128).
 // Not supported (returns RENE_ERR_UNSUPPORTED, never a silent fallback): blackbody / spectrum
-// colours, JPEG image files (out of scope).
+// colours (out of scope).
 #include <zlib.h>
 #include <algorithm>
 #include <cmath>
@@ -34,6 +34,7 @@ std::string loop_subdivide(std::vector<rene_vertex>& verts, std::vector<uint32_t
 // image_io.cpp: rows top first; LDR decoders give RGBA8, the EXR one linear f32
 bool decode_tga(const std::string& data, uint32_t& w, uint32_t& h, std::vector<unsigned char>& rgba, std::string& err);
 bool decode_bmp(const std::string& data, uint32_t& w, uint32_t& h, std::vector<unsigned char>& rgba, std::string& err);
+bool decode_jpeg(const std::string& data, uint32_t& w, uint32_t& h, std::vector<unsigned char>& rgba, std::string& err);
 bool decode_exr(const std::string& data, uint32_t& w, uint32_t& h, std::vector<float>& rgba, std::string& err);
 }
 
@@ -927,12 +928,13 @@ struct Builder {
     size_t dot = path.rfind('.');
     std::string ext = dot == std::string::npos ? "" : path.substr(dot + 1);
     if (ext == "png") return load_png(path, file);
-    if (ext == "tga" || ext == "bmp") {  // the `image` crate branch, intermediate_scene.rs:657-675
+    if (ext == "tga" || ext == "bmp" || ext == "jpg" || ext == "jpeg") {  // the `image` crate branch, intermediate_scene.rs:657-675
       std::string bytes = read_file(path), why;
       uint32_t w = 0, h = 0;
       std::vector<unsigned char> px;
-      if (!(ext == "tga" ? rene::decode_tga(bytes, w, h, px, why) : rene::decode_bmp(bytes, w, h, px, why)))
-        fail(RENE_ERR_IO, (ext == "tga" ? "TGA" : "BMP") + std::string(" decode error (") + why + "): " + file);
+      const bool jpg = ext == "jpg" || ext == "jpeg";
+      if (!(ext == "tga" ? rene::decode_tga(bytes, w, h, px, why) : jpg ? rene::decode_jpeg(bytes, w, h, px, why) : rene::decode_bmp(bytes, w, h, px, why)))
+        fail(RENE_ERR_IO, (ext == "tga" ? "TGA" : jpg ? "JPEG" : "BMP") + std::string(" decode error (") + why + "): " + file);
       std::vector<float> rgba((size_t)w * h * 4);
       for (size_t i = 0; i < (size_t)w * h; ++i) {
         for (int k = 0; k < 3; ++k) rgba[i * 4 + k] = inverse_gamma_correct((float)px[i * 4 + k] / 255.0f);

@@ -245,9 +245,9 @@ def test_image_errors(tmp_path, hip_lib):
         with pytest.raises(api.ReneError) as e:
             load(tmp_path, name)
         assert e.value.code == -6 and "decode error" in str(e.value), (name, str(e.value))
-    (tmp_path / "a.jpg").write_bytes(b"\xff\xd8\xff")
+    (tmp_path / "a.gif").write_bytes(b"GIF89a")
     with pytest.raises(api.ReneError) as e:
-        load(tmp_path, "a.jpg")
+        load(tmp_path, "a.gif")
     assert e.value.code == -4  # RENE_ERR_UNSUPPORTED, never a guess
 
 
@@ -381,3 +381,63 @@ def test_png_every_depth_interlacing_and_colour_keys(tmp_path, hip_lib, interlac
     smp = rng.integers(0, 256, (h, w, 3))
     (tmp_path / "p.png").write_bytes(png_bytes(smp, 8, 2, interlace))
     np.testing.assert_array_equal(np.asarray(Image.open(tmp_path / "p.png")), smp.astype(np.uint8))
+
+
+# ------------------------------------------------------------------------------------------------ JPEG
+def _photo(h, w, seed):
+    """Smooth content with some structure: what JPEG is for (pure noise would only measure the quantiser)."""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:h, 0:w]
+    img = np.stack([128 + 100 * np.sin(x / 9.0) * np.cos(y / 13.0), 128 + 90 * np.cos((x + y) / 17.0), 60 + (x * 180 // w)], axis=2)
+    img[h // 3: h // 2, w // 4: w // 2] = (230, 40, 40)  # a hard edge in chroma
+    return np.clip(img + rng.normal(0, 4, img.shape), 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("progressive", [False, True])
+@pytest.mark.parametrize("subsampling", [0, 1, 2])  # 4:4:4, 4:2:2, 4:2:0
+def test_jpeg_against_pil(tmp_path, hip_lib, progressive, subsampling):
+    """Files written by PIL (libjpeg): baseline and progressive, the three usual chroma samplings, sizes that are
+    not multiples of the MCU, grey, restart intervals, optimised Huffman tables.  Compared with PIL's own decode:
+    both sides approximate the same inverse DCT and use the same triangle filters for chroma, so they agree to a
+    couple of levels (the level-exact result is not defined by the standard)."""
+    from PIL import Image
+    for (h, w), kw in (((37, 53), {}), ((64, 48), {"optimize": True}), ((17, 9), {"quality": 95}), ((40, 40), {"restart_marker_blocks": 3})):
+        img = _photo(h, w, h)
+        try:
+            Image.fromarray(img, "RGB").save(tmp_path / "a.jpg", quality=kw.pop("quality", 85), progressive=progressive, subsampling=subsampling, **kw)
+        except TypeError:
+            continue  # a PIL without restart_marker_blocks
+        want = np.asarray(Image.open(tmp_path / "a.jpg").convert("RGBA"), dtype=np.int32)
+        got8 = np.rint(_linear_to_srgb8(load(tmp_path, "a.jpg"))).astype(np.int32)
+        d = np.abs(got8[..., :3] - want[..., :3])
+        assert d.max() <= 3 and d.mean() < 0.6, (h, w, kw, d.max(), d.mean())
+        assert (got8[..., 3] == 255).all()
+    grey = _photo(33, 41, 2)[..., 0]
+    Image.fromarray(grey, "L").save(tmp_path / "g.jpg", quality=90, progressive=progressive)
+    want = np.asarray(Image.open(tmp_path / "g.jpg").convert("RGBA"), dtype=np.int32)
+    got8 = np.rint(_linear_to_srgb8(load(tmp_path, "g.jpg"))).astype(np.int32)
+    assert np.abs(got8 - want).max() <= 2
+
+
+def _linear_to_srgb8(lin):
+    """Undo the loader's inverse gamma to get the decoder's 8-bit output back (alpha is linear already)."""
+    v = np.asarray(lin, np.float64)
+    out = np.where(v <= 0.0031308, v * 12.92, 1.055 * np.power(np.maximum(v, 0), 1 / 2.4) - 0.055) * 255.0
+    out[..., 3] = v[..., 3] * 255.0
+    return out
+
+
+def test_jpeg_errors(tmp_path, hip_lib):
+    from PIL import Image
+    Image.fromarray(_photo(16, 16, 1), "RGB").save(tmp_path / "ok.jpg")
+    good = (tmp_path / "ok.jpg").read_bytes()
+    sof = good.index(b"\xff\xc0")
+    cases = {"sig.jpg": b"XX" + good[2:], "noframe.jpg": good[:sof] + b"\xff\xd9", "twelve.jpg": good[:sof + 4] + b"\x0c" + good[sof + 5:],
+             "arith.jpg": good[:sof + 1] + b"\xc9" + good[sof + 2:], "cmyk.jpg": None}
+    Image.fromarray(np.zeros((8, 8, 4), np.uint8), "CMYK").save(tmp_path / "cmyk.jpg")
+    for name, blob in cases.items():
+        if blob is not None:
+            (tmp_path / name).write_bytes(blob)
+        with pytest.raises(api.ReneError) as e:
+            load(tmp_path, name)
+        assert e.value.code == -6 and "JPEG decode error" in str(e.value), (name, str(e.value))

@@ -313,7 +313,7 @@ def test_png_image_textures(tmp_path, hip_lib):
         np.testing.assert_allclose(got[..., :3], lin[..., :3], rtol=2e-6, atol=1e-7)
         np.testing.assert_array_equal(got[..., 3], v[..., 3])
     # other LDR formats are refused, not guessed (16-bit and interlaced PNG: tests/test_images.py)
-    for name, code in (("missing.png", -6), ("x.jpg", -4)):
+    for name, code in (("missing.png", -6), ("x.gif", -4)):
         (tmp_path / "bad.pbrt").write_text(f'WorldBegin\nTexture "t" "spectrum" "imagemap" "string filename" "{name}"\nWorldEnd\n')
         with pytest.raises(api.ReneError) as e:
             loader.load_pbrt(str(tmp_path / "bad.pbrt"))
