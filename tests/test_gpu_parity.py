@@ -263,3 +263,25 @@ def test_overlap_with_shards_resets_and_a_caller_owned_image():
         with api.Renderer(s) as q:
             q.render(0, 9)
             assert np.array_equal(r.download(0), q.download(0))
+
+
+def test_cornell_512_at_64_spp_overlapped_and_tuned_against_the_oracle(oracle_mod):
+    """The configuration the bench runs in -- overlapping launches, work items cut by rene_tune -- at a size the
+    oracle still finishes in seconds on the box's host cores (17 M paths): T1 on all three layers, counters equal
+    to a few paths that forked, mean radiance within 2e-4."""
+    s = scenes.cornell_box(512, 512)
+    o = oracle_mod.Oracle(s)
+    o.render(0, 64, threads=min(16, len(os.sched_getaffinity(0))))
+    with api.Renderer(s, flags=abi.FLAG_OVERLAP | abi.FLAG_COUNTERS) as r:
+        r.tune(16)
+        for k in range(4):
+            r.render(16 * k, 16)
+        so, sg = o.stats().as_dict(), r.stats().as_dict()
+        assert sg["paths"] == so["paths"] == 512 * 512 * 64
+        for k in ("rays_closest", "rays_emitter", "hits", "adds"):
+            assert abs(sg[k] - so[k]) <= 1e-4 * so[k] + 2, (k, sg[k], so[k])
+        g, c = r.download(0), o.download(0)
+        t1_check(g, c, frac=2e-3, relmse=1e-4)  # 64 frames of accumulated forks: twice the 8-frame budget
+        assert abs(float(g.sum() / c.sum()) - 1) < 2e-4
+        aov_check(r.download(1), o.download(1), atol=2e-5 * 64)
+        aov_check(r.download(2), o.download(2), atol=1e-6 * 64)
