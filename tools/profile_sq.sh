@@ -1,13 +1,13 @@
 #!/bin/bash
-# two SQ counter passes over a short bench run; prints per-launch averages for the render kernel
-R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out; TAG=${1:-sq}
+# usage: tools/profile_sq.sh TAG script.py [args]  -> SQ counters of the render kernels (one pass, the set profile_bench.sh uses)
+R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out; TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INST_CYCLES_SALU SQ_INSTS_SMEM SQ_INST_CYCLES_SMEM SQ_INSTS_BRANCH -d $OUT/prof_${TAG}_a -o a -- python3 $R/bench.py --steps 8 --warmup 1 --no-cpu-baseline > $OUT/prof_${TAG}_a.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INSTS_VALU_TRANS_F32 SQ_IFETCH -d $OUT/prof_${TAG}_b -o b -- python3 $R/bench.py --steps 8 --warmup 1 --no-cpu-baseline > $OUT/prof_${TAG}_b.log 2>&1
+timeout -k 5 120 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY -d $OUT/prof_${TAG}_sq -o p -- python3 $R/$1 $2 $3 > $OUT/prof_${TAG}_sq.log 2>&1 || { echo "pass failed"; grep -m2 -i "error\|exceeds" $OUT/prof_${TAG}_sq.log; exit 1; }
+grep -h "megakernel" $OUT/prof_${TAG}_sq.log
 python3 - <<PY
-import sqlite3
-for sub in ("a","b"):
-    db=sqlite3.connect("$OUT/prof_${TAG}_%s/%s_results.db"%(sub,sub)); cur=db.cursor()
-    for row in cur.execute("select counter_name, count(*), avg(value), avg(duration) from counters_collection where kernel_name like '%render_kernel<72u, 1, false%' group by counter_name"):
-        print(f"{row[0]:<28} n={row[1]:<3} avg={row[2]:.4g}  dur_ms={row[3]/1e6:.2f}")
+import sqlite3, os
+p = "$OUT/prof_${TAG}_sq/p_results.db"
+db = sqlite3.connect(p)
+for row in db.execute("select kernel_name, counter_name, count(*), sum(value), avg(duration) from counters_collection group by kernel_name, counter_name"):
+    if "rene::" in row[0]: print(row[1], "n=%d sum=%.6g avg_dur_us=%.1f" % (row[2], row[3], row[4]/1e3), row[0][:60])
 PY
