@@ -180,7 +180,8 @@ int main(int argc, char** argv) {
     o.shard_mode = RENE_SHARD_TILES;
     o.shard_rank = g;
     o.shard_count = gpus;
-    if (aov_normal.empty() && aov_albedo.empty()) o.flags |= RENE_FLAG_NO_AOV;
+    // all three layers are accumulated whether or not --aov-* asks for the files, like the reference's raygen
+    // (lib.rs:229-232); RENE_FLAG_NO_AOV would save little and its Matte item-loop kernel happens to be the slower one
     // batches overlap on two streams (same image bit for bit): rene_render returns once the batch before the
     // previous one has finished, so the progress line lags the device by at most two batches
     o.flags |= RENE_FLAG_OVERLAP;
