@@ -28,6 +28,8 @@ hipError_t launch_render_bvh(const LaunchConfig& cfg, const SceneView& S, const 
   const uint32_t f = cfg.features;
   if (!(f & (FEAT_SPHERES | FEAT_GENERAL_BSDF | FEAT_TEXTURES | FEAT_BACKGROUND | FEAT_MULTI_LOBE)))
     return launch_bvh<FEAT_LIGHTS, 1>(cfg, S, P, st);
+  // general single-lobe scenes without spheres and distant lights (teapot-class: Substrate + textures + environment map)
+  if (!(f & (FEAT_MULTI_LOBE | FEAT_SPHERES | FEAT_LIGHTS))) return launch_bvh<FEAT_GENERAL_BSDF | FEAT_TEXTURES | FEAT_BACKGROUND, 1>(cfg, S, P, st);
   if (!(f & FEAT_MULTI_LOBE)) return launch_bvh<GEN1, 1>(cfg, S, P, st);
   return launch_bvh<ALL, 5>(cfg, S, P, st);
 }
