@@ -129,6 +129,9 @@ hipError_t launch_render(const LaunchConfig& cfg, const SceneView& S, const Rend
   if (!(f & FEAT_SMALL)) return launch_render_bvh(cfg, S, P, st);  // kernels_bvh.hip
   if (!(f & (FEAT_SPHERES | FEAT_GENERAL_BSDF | FEAT_TEXTURES | FEAT_BACKGROUND | FEAT_MULTI_LOBE)))
     return launch_small<FEAT_LIGHTS | FEAT_SMALL, 1>(cfg, S, P, st);
+  // general single-lobe scenes without textures, distant lights or a background (veach-mis: Matte + Metal, sphere emitters)
+  if (!(f & (FEAT_MULTI_LOBE | FEAT_TEXTURES | FEAT_LIGHTS | FEAT_BACKGROUND)))
+    return launch_small<FEAT_SPHERES | FEAT_GENERAL_BSDF | FEAT_SMALL, 1>(cfg, S, P, st);
   if (!(f & FEAT_MULTI_LOBE)) return launch_small<GEN1 | FEAT_SMALL, 1>(cfg, S, P, st);
   return launch_small<ALL | FEAT_SMALL, 5>(cfg, S, P, st);
 }

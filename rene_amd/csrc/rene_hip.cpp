@@ -111,7 +111,7 @@ struct rene_ctx {
     return e;
   }
   std::deque<Pending> pending;
-  uint64_t frames = 0, launches = 0;
+  uint64_t frames = 0, launches = 0, owned_pixels = 0, paths = 0;
   double kernel_ms = 0.0, last_ms = 0.0;
   // seed schedule cache: seeds[k] = k-th next_u32 of PCG32si::new(master)
   std::vector<uint32_t> seed_cache;
@@ -244,6 +244,8 @@ int rene_create(const rene_scene_desc* scene, const rene_opts* opts, rene_ctx** 
   if (n_dev <= 0) return fail(RENE_ERR_DEVICE, "no HIP device visible (the render path has no CPU fallback)");
   if (o.device < 0 || o.device >= n_dev) return fail(RENE_ERR_INVALID_ARGUMENT, "device ordinal out of range");
   HIP_TRY(hipSetDevice(o.device));
+  if (ps.width > 65535u || ps.height > 65535u)  // a lane keeps its pixel as x | y << 16
+    return fail(RENE_ERR_INVALID_ARGUMENT, "resolutions above 65535 are not supported");
 
   std::unique_ptr<rene_ctx> c(new rene_ctx());
   c->device = o.device;
@@ -345,6 +347,12 @@ int rene_create(const rene_scene_desc* scene, const rene_opts* opts, rene_ctx** 
   }
   uint32_t owned = c->n_tiles > tile_rank ? (c->n_tiles - tile_rank + tile_count - 1) / tile_count : 0;
   c->n_work = owned * RENE_TILE_SIZE * RENE_TILE_SIZE;
+  // pixels of the image inside the owned tiles: paths per rendered frame (the kernels do not count what the host knows)
+  c->owned_pixels = 0;
+  for (uint32_t t = tile_rank; t < c->n_tiles; t += tile_count) {
+    const uint32_t x0 = (t % c->tiles_x) * RENE_TILE_SIZE, y0 = (t / c->tiles_x) * RENE_TILE_SIZE;
+    c->owned_pixels += (uint64_t)std::min<uint32_t>(RENE_TILE_SIZE, ps.width - x0) * std::min<uint32_t>(RENE_TILE_SIZE, ps.height - y0);
+  }
 
   c->fb_floats = (size_t)3 * ps.width * ps.height * 4;
   if (o.framebuffer) {
@@ -448,6 +456,7 @@ int rene_render(rene_ctx* c, uint32_t first_frame, uint32_t n_frames) {
   }
   c->frames += n_frames;
   if (seeds.empty() || c->n_work == 0) return RENE_OK;
+  c->paths += (uint64_t)seeds.size() * c->owned_pixels;
 
   if (c->epoch >= (1u << 27) - 1u) {  // the hand-off flags are cleared when the epoch wraps: nothing may be in flight then
     int rc = c->drain();
@@ -590,6 +599,7 @@ int rene_reset(rene_ctx* c) {
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->prev_final = 0;  // the pixel records carry version 0 again
   c->frames = 0;
+  c->paths = 0;
   c->launches = 0;
   c->kernel_ms = 0.0;
   c->last_ms = 0.0;
@@ -674,7 +684,7 @@ int rene_get_stats(rene_ctx* c, rene_stats* out) {
   out->rays_closest = h[0];
   out->rays_shadow = h[1];
   out->rays_emitter = h[2];
-  out->paths = h[3];
+  out->paths = c->paths;  // frames rendered x pixels owned
   out->hits = h[4];
   out->bounces = h[4];
   out->adds = h[5];
