@@ -127,6 +127,8 @@ hipError_t launch_render(const LaunchConfig& cfg, const SceneView& S, const Rend
   const uint32_t f = cfg.features;
   if (f & FEAT_VOLPATH) return launch_render_vol(cfg, S, P, st);   // kernels_vol.hip
   if (!(f & FEAT_SMALL)) return launch_render_bvh(cfg, S, P, st);  // kernels_bvh.hip
+  if (!(f & (FEAT_SPHERES | FEAT_GENERAL_BSDF | FEAT_TEXTURES | FEAT_BACKGROUND | FEAT_MULTI_LOBE | FEAT_LIGHTS)))
+    return launch_small<FEAT_SMALL, 1>(cfg, S, P, st);  // Matte, triangle emitters only (Cornell)
   if (!(f & (FEAT_SPHERES | FEAT_GENERAL_BSDF | FEAT_TEXTURES | FEAT_BACKGROUND | FEAT_MULTI_LOBE)))
     return launch_small<FEAT_LIGHTS | FEAT_SMALL, 1>(cfg, S, P, st);
   // general single-lobe scenes without textures, distant lights or a background (veach-mis: Matte + Metal, sphere emitters)
