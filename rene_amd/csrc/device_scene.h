@@ -205,6 +205,12 @@ enum : uint32_t {
   FEAT_MULTI_LOBE = 1u << 5,   // Plastic / Uber (more than one lobe)
   FEAT_SMALL = 1u << 6,        // both structures fit the wave-coherent item loop (no BVH traversal)
   FEAT_VOLPATH = 1u << 7,      // Integrator "volpath": media, None-material boundaries, depth 80, no roulette
+  // what a general-BSDF scene does NOT contain (set only together with FEAT_GENERAL_BSDF, never with FEAT_MULTI_LOBE):
+  // a kernel instantiated with these bits leaves the lobe kinds out, which is worth an occupancy step
+  FEAT_NO_SPECULAR = 1u << 8,    // no Glass, no Mirror (FresnelSpecular / SpecularReflection / SpecularTransmission lobes)
+  FEAT_NO_BLEND = 1u << 9,       // no Substrate (FresnelBlend lobe)
+  FEAT_NO_MICROFACET = 1u << 10, // no Metal (MicrofacetReflection lobe)
+  FEAT_ABSENT_MASK = FEAT_NO_SPECULAR | FEAT_NO_BLEND | FEAT_NO_MICROFACET,
 };
 
 struct RenderParams {

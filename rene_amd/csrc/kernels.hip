@@ -58,10 +58,11 @@ __global__ void __launch_bounds__(64) bsdf_eval_kernel(SceneView S, uint32_t mat
   b.onb = onb_from_w(normal);
   compute_bsdf<ALL, 5>(S, inst, uv2{uv2_[2 * i], uv2_[2 * i + 1]}, b);
   f3 wo = mk3(wo3[3 * i], wo3[3 * i + 1], wo3[3 * i + 2]), wi = mk3(wi3[3 * i], wi3[3 * i + 1], wi3[3 * i + 2]);
-  f3 f = bsdf_f<5, true>(b, wo, wi);
-  float p = b.len ? bsdf_pdf<5, true>(b, wo, wi) : 0.0f;
+  constexpr uint32_t KINDS = lobe_kinds(ALL);  // every lobe kind
+  f3 f = bsdf_f<5, KINDS>(b, wo, wi);
+  float p = b.len ? bsdf_pdf<5, KINDS>(b, wo, wi) : 0.0f;
   Pcg rng = pcg_new(seeds[i]);
-  Sampled sf = bsdf_sample<5, true>(b, wo, rng);
+  Sampled sf = bsdf_sample<5, KINDS>(b, wo, rng);
   float* o = out + 12 * (size_t)i;
   o[0] = f.x; o[1] = f.y; o[2] = f.z; o[3] = p;
   o[4] = sf.wi.x; o[5] = sf.wi.y; o[6] = sf.wi.z;
@@ -131,9 +132,13 @@ hipError_t launch_render(const LaunchConfig& cfg, const SceneView& S, const Rend
     return launch_small<FEAT_SMALL, 1>(cfg, S, P, st);  // Matte, triangle emitters only (Cornell)
   if (!(f & (FEAT_SPHERES | FEAT_GENERAL_BSDF | FEAT_TEXTURES | FEAT_BACKGROUND | FEAT_MULTI_LOBE)))
     return launch_small<FEAT_LIGHTS | FEAT_SMALL, 1>(cfg, S, P, st);
-  // general single-lobe scenes without textures, distant lights or a background (veach-mis: Matte + Metal, sphere emitters)
-  if (!(f & (FEAT_MULTI_LOBE | FEAT_TEXTURES | FEAT_LIGHTS | FEAT_BACKGROUND)))
+  // general single-lobe scenes without textures, distant lights or a background (veach-mis: Matte + Metal, sphere
+  // emitters); with Metal as the only general material the other lobe kinds are compiled out: 118 VGPRs, four waves
+  if (!(f & (FEAT_MULTI_LOBE | FEAT_TEXTURES | FEAT_LIGHTS | FEAT_BACKGROUND))) {
+    if ((f & FEAT_NO_SPECULAR) && (f & FEAT_NO_BLEND))
+      return launch_small<FEAT_SPHERES | FEAT_GENERAL_BSDF | FEAT_SMALL | FEAT_NO_SPECULAR | FEAT_NO_BLEND, 1>(cfg, S, P, st);
     return launch_small<FEAT_SPHERES | FEAT_GENERAL_BSDF | FEAT_SMALL, 1>(cfg, S, P, st);
+  }
   if (!(f & FEAT_MULTI_LOBE)) return launch_small<GEN1 | FEAT_SMALL, 1>(cfg, S, P, st);
   return launch_small<ALL | FEAT_SMALL, 5>(cfg, S, P, st);
 }

@@ -29,7 +29,11 @@ hipError_t launch_render_bvh(const LaunchConfig& cfg, const SceneView& S, const 
   if (!(f & (FEAT_SPHERES | FEAT_GENERAL_BSDF | FEAT_TEXTURES | FEAT_BACKGROUND | FEAT_MULTI_LOBE)))
     return launch_bvh<FEAT_LIGHTS, 1>(cfg, S, P, st);
   // general single-lobe scenes without spheres and distant lights (teapot-class: Substrate + textures + environment map)
-  if (!(f & (FEAT_MULTI_LOBE | FEAT_SPHERES | FEAT_LIGHTS))) return launch_bvh<FEAT_GENERAL_BSDF | FEAT_TEXTURES | FEAT_BACKGROUND, 1>(cfg, S, P, st);
+  if (!(f & (FEAT_MULTI_LOBE | FEAT_SPHERES | FEAT_LIGHTS))) {
+    if ((f & FEAT_NO_SPECULAR) && (f & FEAT_NO_MICROFACET))  // ... and Substrate as the only general material
+      return launch_bvh<FEAT_GENERAL_BSDF | FEAT_TEXTURES | FEAT_BACKGROUND | FEAT_NO_SPECULAR | FEAT_NO_MICROFACET, 1>(cfg, S, P, st);
+    return launch_bvh<FEAT_GENERAL_BSDF | FEAT_TEXTURES | FEAT_BACKGROUND, 1>(cfg, S, P, st);
+  }
   if (!(f & FEAT_MULTI_LOBE)) return launch_bvh<GEN1, 1>(cfg, S, P, st);
   return launch_bvh<ALL, 5>(cfg, S, P, st);
 }

@@ -668,6 +668,7 @@ int pack_scene(const rene_scene_desc* d, PackedScene& out, std::string& err) {
 
   // ---- tables ----
   out.materials.resize(d->n_materials);
+  uint32_t lobe_kinds = 0;  // 1 specular (Glass / Mirror), 2 FresnelBlend (Substrate), 4 microfacet (Metal)
   for (uint32_t i = 0; i < d->n_materials; ++i) {
     const rene_material& m = d->materials[i];
     Material& o = out.materials[i];
@@ -696,6 +697,14 @@ int pack_scene(const rene_scene_desc* d, PackedScene& out, std::string& err) {
       if (refs[k] >= d->n_textures) { err = "material references a texture out of range"; return RENE_ERR_INVALID_SCENE; }
     if (m.type != RENE_MATERIAL_NONE && m.type != RENE_MATERIAL_MATTE) out.features |= FEAT_GENERAL_BSDF;
     if (m.type == RENE_MATERIAL_UBER || m.type == RENE_MATERIAL_PLASTIC) out.features |= FEAT_MULTI_LOBE;
+    if (m.type == RENE_MATERIAL_GLASS || m.type == RENE_MATERIAL_MIRROR) lobe_kinds |= 1u;
+    if (m.type == RENE_MATERIAL_SUBSTRATE) lobe_kinds |= 2u;
+    if (m.type == RENE_MATERIAL_METAL) lobe_kinds |= 4u;
+  }
+  if ((out.features & FEAT_GENERAL_BSDF) && !(out.features & FEAT_MULTI_LOBE)) {  // what the single-lobe scene leaves out
+    if (!(lobe_kinds & 1u)) out.features |= FEAT_NO_SPECULAR;
+    if (!(lobe_kinds & 2u)) out.features |= FEAT_NO_BLEND;
+    if (!(lobe_kinds & 4u)) out.features |= FEAT_NO_MICROFACET;
   }
   out.textures.resize(d->n_textures);
   for (uint32_t i = 0; i < d->n_textures; ++i) {
