@@ -51,6 +51,20 @@ struct HostPcg {
     uint32_t w = ((o >> ((o >> 28) + 4u)) ^ o) * 277803737u;
     return (w >> 22) ^ w;
   }
+  // n steps at once (the LCG's n-fold composition by repeated squaring): frame k's seed is the k-th output, and a
+  // caller may ask for frame four billion without anybody having produced the ones before it
+  void skip(uint64_t n) {
+    uint32_t mul = 747796405u, add = 2891336453u, acc_mul = 1u, acc_add = 0u;
+    for (; n; n >>= 1) {
+      if (n & 1u) {
+        acc_mul *= mul;
+        acc_add = acc_add * mul + add;
+      }
+      add = (mul + 1u) * add;
+      mul *= mul;
+    }
+    s = acc_mul * s + acc_add;
+  }
 };
 
 }  // namespace
@@ -114,8 +128,6 @@ struct rene_ctx {
   uint64_t frames = 0, launches = 0, owned_pixels = 0, paths = 0;
   double kernel_ms = 0.0, last_ms = 0.0;
   // seed schedule cache: seeds[k] = k-th next_u32 of PCG32si::new(master)
-  std::vector<uint32_t> seed_cache;
-  HostPcg seed_gen{0};
 
   template <class T>
   int upload(const std::vector<T>& v, const T** out) {
@@ -183,7 +195,7 @@ uint32_t rene_abi_version(void) { return RENE_ABI_VERSION; }
 
 void rene_frame_seeds(uint32_t master_seed, uint32_t first_frame, uint32_t n, uint32_t* out) {
   HostPcg g(master_seed);
-  for (uint32_t k = 0; k < first_frame; ++k) g.next();
+  g.skip(first_frame);
   for (uint32_t k = 0; k < n; ++k) out[k] = g.next();
 }
 
@@ -250,7 +262,6 @@ int rene_create(const rene_scene_desc* scene, const rene_opts* opts, rene_ctx** 
   std::unique_ptr<rene_ctx> c(new rene_ctx());
   c->device = o.device;
   c->opts = o;
-  c->seed_gen = HostPcg(o.seed);
   c->width = ps.width;
   c->height = ps.height;
   c->n_materials = (uint32_t)ps.materials.size();
@@ -444,15 +455,17 @@ int rene_render(rene_ctx* c, uint32_t first_frame, uint32_t n_frames) {
   if ((uint64_t)first_frame + n_frames > 0xffffffffull) return fail(RENE_ERR_INVALID_ARGUMENT, "frame range overflows u32");
   HIP_TRY(hipSetDevice(c->device));
   // seed schedule: frame k -> k-th next_u32 of PCG32si::new(master)
-  while (c->seed_cache.size() < (size_t)first_frame + n_frames) c->seed_cache.push_back(c->seed_gen.next());
+  HostPcg gen(c->opts.seed);
+  gen.skip(first_frame);
   std::vector<uint32_t> seeds;
   seeds.reserve(n_frames);
   for (uint32_t k = 0; k < n_frames; ++k) {
     uint32_t f = first_frame + k;
+    const uint32_t seed_k = gen.next();
     if (c->opts.shard_mode == RENE_SHARD_FRAMES && c->opts.shard_count > 1 &&
         f % c->opts.shard_count != c->opts.shard_rank)
       continue;
-    seeds.push_back(c->seed_cache[f]);
+    seeds.push_back(seed_k);
   }
   c->frames += n_frames;
   if (seeds.empty() || c->n_work == 0) return RENE_OK;

@@ -68,6 +68,10 @@ def test_frame_seeds_follow_pcg_schedule(hip_lib, oracle_mod):
     got = api.frame_seeds(abi.DEFAULT_SEED, 0, 8)
     assert got.tolist() == oracle_mod.pcg_u32(abi.DEFAULT_SEED, 8).tolist()
     assert api.frame_seeds(7, 5, 3).tolist() == oracle_mod.pcg_u32(7, 8)[5:].tolist()
+    # the k-th seed comes from jumping the generator ahead, not from producing its predecessors: far frames cost nothing
+    far = api.frame_seeds(7, 4_000_000_000, 6)
+    assert far[4:].tolist() == api.frame_seeds(7, 4_000_000_004, 2).tolist()
+    assert api.frame_seeds(7, 100_000, 4).tolist() == oracle_mod.pcg_u32(7, 100_004)[100_000:].tolist()
 
 
 def test_output_transform_matches_restatement(hip_lib, oracle_mod):
