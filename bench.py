@@ -1,34 +1,39 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the render hot path (BASELINE.json: Mrays/s and ms/frame at
-fixed spp; achieved GB/s vs the HBM roofline).
+fixed spp; achieved rate against the roofline that binds).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--only NAME] [--no-configs] [--no-cpu-baseline]
 
-Workload: BASELINE.json configs[1], "Cornell-box 1024x1024 @ 1024 spp, 1x MI355X" (synthetic
-Cornell-box-shaped scene built in code, rene_amd/scenes.py).  A *step* is one launch of the
-persistent render kernel over every pixel this rank owns for `frames_per_step = ceil(1024 / K)`
-frames, so the K timed steps always render the full 1024 spp (a little more if K does not divide
-1024).  Default K = 4, i.e. 256 frames per launch: a launch ends with its longest paths and a partly idle chip, so
-fewer, longer launches are the efficient way to ask for 1024 spp (measured, Grays/s at K = 16 / 8 / 4 / 2:
-82.6 / 86.8 / 91.2 / 88.0 -- at K = 2 there is no third launch to hide the second one's tail).  Consecutive
-launches overlap on two streams (RENE_FLAG_OVERLAP) and the work-item granularity is picked by rene_tune in the
-untimed part; neither changes a bit of the image.  Inputs (scene tables, BVH, frame seeds) are resident in HBM
-before the timed region.
+Headline workload: BASELINE.json configs[1], "Cornell-box 1024x1024 @ 1024 spp, 1x MI355X" (synthetic
+Cornell-box-shaped scene built in code, rene_amd/scenes.py).  A *step* is one whole such job: clear the
+accumulation image (rene/src/main.rs:1229-1237), render all 1024 frames of every pixel as launches of 256
+frames of the persistent kernel (two launches in flight, RENE_FLAG_OVERLAP), wait for the last launch.  The K timed
+steps are K jobs back to back, each timed on its own as well: `step_ms_median` / `step_ms_min`.  Every job renders the
+same frames, so its image must be bit-identical to the first one's -- checked after the timed region.  Inputs (scene tables,
+BVH, frame seeds) are resident in HBM before the timed region; `value` = rays of all K jobs / elapsed.
 
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL).  Strong scaling: the job is still
-K steps = 1024 spp of the whole image; its K * frames_per_step frames are dealt to the ranks in N
-contiguous blocks (rene_amd.dist.frame_block), each rank renders its block in launches of at most
-frames_per_step frames (two when the block would fit one, so that they overlap), ranks never talk while rendering, and the one exchange step -- an RCCL reduce
-(sum) of the [3][H][W][4] f32 partial images onto rank 0 -- is inside the timed region.
-RENE_BENCH_SHARD=tiles selects the other cut (32x32 tiles round-robin + a gather of owned tiles: bit-
-identical to one GPU, but a rank's launches shrink with N).  value = rays of all ranks / max-over-ranks time.
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL).  Strong scaling: the job is still 1024 spp
+of the whole image; its frames are dealt to the ranks in N contiguous blocks (rene_amd.dist.frame_block), each rank
+renders its block in at least two launches, ranks never talk while rendering, and the one exchange step of a job -- an
+RCCL reduce (sum) of the [3][H][W][4] f32 partial images onto rank 0 -- is inside the job, hence inside the timed
+region.  RENE_BENCH_SHARD=tiles selects north_star's cut (32x32 tiles round-robin + a gather of owned tiles:
+bit-identical to one GPU, but a rank's launches shrink with N; DESIGN.md section 6 has the measurement behind
+the default).  value = rays of all ranks / max-over-ranks time.
 
 The JSON line also carries
-  roofline     -- dominant kernel (render_kernel): algorithmic bytes per launch (SURVEY.md 8d cache-less
-                  model, evaluated from the node/primitive counters of an untimed counting pass over
-                  this build's BVH4) / average launch duration from HIP events recorded on the
-                  kernel's stream inside librene_hip.so, against the 8 TB/s HBM3E peak; `traffic` =
-                  PMC-measured HBM bytes per launch when profiles/ holds them for this config;
+  roofline     -- for the dominant kernel of the headline job.  The kernel is bound by VALU issue, not by HBM (the
+                  36-triangle scene is cache resident): `bound` = "valu", `achieved` = lane-operations per
+                  second = rays/s x VALU wave-instructions per ray x 64, transcendentals counted twice (they
+                  issue at half rate), `peak` = 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6 T lane-ops/s (a wave64
+                  VALU instruction takes a SIMD two cycles; MI355X_MICROARCH.md "Wave scheduling").  Instruction
+                  counts per ray come from the committed rocprofv3 PMC passes (profiles/pmc_per_ray.json:
+                  per RAY, so they hold whatever K is); rates are measured live.  `hbm` inside it = the measured
+                  HBM bytes per ray (FETCH_SIZE x 2 + WRITE_SIZE, same passes) x live rays/s against 8 TB/s, and
+                  SURVEY 8d's cache-less algorithmic bytes for comparison (not a fraction of anything: the scene
+                  lives in the caches).  `traffic` = measured HBM bytes per launch.
+  configs      -- N = 1 only: the other BASELINE configurations that fit one GPU, one full job each at its own
+                  resolution and sample count (C3 veach-mis 1024x1024 @ 4096 spp, C4 dragon-class 1920x1080 @ 1024 spp,
+                  C5 teapot-class 1920x1080 @ 8192 spp), each with rays, Mrays/s, ms/frame and the same two fractions.
   cpu_baseline -- the CPU oracle (a port of rene's integrator; the reference itself has no CPU
                   path and cannot be built here) timed on this host's cores on a bounded sample.
 """
@@ -38,6 +43,7 @@ import argparse
 import json
 import math
 import os
+import statistics
 import sys
 import time
 
@@ -45,59 +51,79 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-WIDTH = HEIGHT = 1024
-TARGET_SPP = 1024
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+CLOCK_GHZ = 2.4          # peak engine clock, same guide
+SIMDS_PER_CU = 4
+LANES_PER_SIMD_CYCLE = 32  # SIMD-32: a wave64 VALU instruction occupies its SIMD for 2 cycles
 
 
-def pmc_record(frames_per_step: int, n_gpus: int):
-    """The rocprofv3 --pmc summary committed under profiles/ for this launch shape (None if absent or
-    collected for a different shape): HBM bytes per render_kernel launch (FETCH_SIZE doubled per the
-    gfx950 correction, WRITE_SIZE as is) and the SQ_* instruction counts of the same launch."""
-    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+def configurations():
+    """name -> (label, scene factory, spp of one job, frames per launch).  The headline is first."""
+    from rene_amd import scenes
+    return {
+        "cornell": ("cornell-box 1024x1024 @ 1024 spp", lambda: scenes.cornell_box(1024, 1024), 1024, 256),
+        "veach-mis": ("veach-mis 1024x1024 @ 4096 spp", lambda: scenes.veach_mis(1024, 1024), 4096, 256),
+        "dragon-class": ("dragon-class (870 400 triangles, one distant light) 1920x1080 @ 1024 spp", lambda: scenes.dragon_class(1920, 1080), 1024, 64),
+        "teapot-class": ("teapot-full-class (126 048 triangles, Substrate + checkerboard + env map) 1920x1080 @ 8192 spp",
+                         lambda: scenes.teapot_class(1920, 1080), 8192, 128),
+    }
+
+
+def pmc_per_ray(name: str):
+    """The per-ray figures of the committed rocprofv3 PMC passes for this configuration (tools/prof.sh +
+    tools/summarize_profiles.py), or None."""
     try:
-        rec = json.load(open(path))
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc_per_ray.json"))).get(name)
     except Exception:
         return None
-    if rec.get("frames_per_step") != frames_per_step or rec.get("n_gpus", 1) != n_gpus:
-        return None
-    return rec
 
 
-def pmc_traffic(frames_per_step: int, n_gpus: int):
-    rec = pmc_record(frames_per_step, n_gpus)
-    return rec.get("hbm_bytes_per_launch") if rec else None
+def rooflines(name: str, rays_per_s: float, cus: int, alg_bytes_per_ray: float | None):
+    """VALU-issue and HBM fractions of one configuration at the measured ray rate."""
+    rec = pmc_per_ray(name)
+    peak_lane_ops = cus * SIMDS_PER_CU * LANES_PER_SIMD_CYCLE * CLOCK_GHZ * 1e9
+    out = {"valu": None, "hbm": None}
+    if rec and rec.get("valu_wave_insts_per_ray"):
+        w = rec["valu_wave_insts_per_ray"] + (rec.get("trans_wave_insts_per_ray") or 0.0)  # transcendentals: half rate
+        ach = rays_per_s * w * 64.0
+        out["valu"] = {"achieved": ach / 1e12, "peak": peak_lane_ops / 1e12, "unit": "Tlane-op/s", "frac": ach / peak_lane_ops,
+                       "lane_ops_per_ray": rec["valu_wave_insts_per_ray"] * 64.0,
+                       "trans_lane_ops_per_ray": (rec.get("trans_wave_insts_per_ray") or 0.0) * 64.0,
+                       "lanes_active": rec.get("valu_lanes_active"), "wait_any_frac": rec.get("wait_any_frac"),
+                       "source": rec.get("source")}
+    if rec and rec.get("hbm_read_bytes_per_ray") is not None:
+        b = rec["hbm_read_bytes_per_ray"] + rec["hbm_write_bytes_per_ray"]
+        out["hbm"] = {"achieved": rays_per_s * b / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                      "frac": rays_per_s * b / 1e9 / HBM_PEAK_GBPS, "measured_bytes_per_ray": b,
+                      "algorithmic_bytes_per_ray": alg_bytes_per_ray,
+                      "algorithmic_GBps_cacheless": rays_per_s * alg_bytes_per_ray / 1e9 if alg_bytes_per_ray else None,
+                      "source": rec.get("source")}
+    return out
 
 
-def valu_issue(frames_per_step: int, n_gpus: int, launch_ms: float, cus: int, clock_ghz: float):
-    """What actually bounds the kernel: the share of VALU issue cycles in use.  A wave64 VALU
-    instruction occupies its SIMD16 for 4 cycles; there are 4 SIMDs per CU.  Instruction count from the
-    committed PMC pass (SQ_INSTS_VALU per launch), duration measured live."""
-    rec = pmc_record(frames_per_step, n_gpus)
-    if not rec or not rec.get("valu_wave_insts_per_launch") or launch_ms <= 0:
-        return None
-    insts = rec["valu_wave_insts_per_launch"]
-    avail = cus * 4 * launch_ms * 1e-3 * clock_ghz * 1e9
-    return {"valu_wave_insts_per_launch": insts, "issue_cycles_frac": insts * 4.0 / avail,
-            "lane_ops_per_ray": None, "clock_ghz": clock_ghz, "cus": cus,
-            "source": f"profiles/{rec.get('tag', '')}_pmc.txt (SQ_INSTS_VALU) / live launch period",
-            "model": "4 issue cycles per wave64 VALU instruction at the nominal clock; a fraction above 1 says the hardware "
-                     "retires some of them faster (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.03 quad-cycles per instruction "
-                     "over a launch that is not busy throughout) -- the issue slots are full either way"}
+def algorithmic_bytes_per_ray(packed, api, abi, device, frames=4, **shard):
+    """SURVEY 8d's cache-less model, evaluated from the kernel's own node / primitive counters over this build's
+    BVH4 (RENE_FLAG_FORCE_BVH, so that the figure does not depend on which intersection back end renders the scene)."""
+    with api.Renderer(packed, device=device, flags=abi.FLAG_COUNTERS | abi.FLAG_FORCE_BVH, **shard) as rc:
+        rc.render(0, frames)
+        cst = rc.stats()
+    return abi.algorithmic_bytes(cst) / max(1, cst.rays)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--only", default=None, help="run this configuration as the timed workload instead of the headline (profiling)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the additional configurations (C3-C5)")
     ap.add_argument("--cpu-spp", type=int, default=128, help="frames of the CPU-oracle baseline sample (~10 s on 16 threads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
     import numpy as np
     import torch
-    from rene_amd import abi, api, dist as rdist, scenes
+    from rene_amd import abi, api, dist as rdist
 
     rank, world, local = rdist.env_rank_world()
     if world != max(1, args.gpus) and world != 1:
@@ -114,24 +140,29 @@ def main():
         rdist.init_process_group(backend)
         import torch.distributed as dist
 
+    cfgs = configurations()
+    head = args.only or "cornell"
+    if head not in cfgs:
+        raise SystemExit(f"--only: unknown configuration {head!r} (have {', '.join(cfgs)})")
+    label, make, SPP, F = cfgs[head]
     K, Wm = max(1, args.steps), max(0, args.warmup)
-    F = math.ceil(TARGET_SPP / K)
-    scene = scenes.cornell_box(WIDTH, HEIGHT)
+    scene = make()
     packed = scene.to_desc()
+    WIDTH, HEIGHT = packed.xres, packed.yres
 
     by_tiles = os.environ.get("RENE_BENCH_SHARD", "frames") == "tiles"
     t_rank, t_world = (rank, world) if by_tiles else (0, 1)
+    shard = dict(shard_mode=abi.SHARD_TILES, shard_rank=t_rank, shard_count=t_world)
     fb = torch.zeros((3, HEIGHT, WIDTH, 4), dtype=torch.float32, device=f"cuda:{local}")
     # consecutive launches overlap on two streams (the next one fills the chip while the last paths of the previous
     # one finish; same image bit for bit) unless RENE_BENCH_OVERLAP=0
     overlap = abi.FLAG_OVERLAP if os.environ.get("RENE_BENCH_OVERLAP", "1") != "0" else 0
-    r = api.Renderer(packed, device=local, flags=overlap, shard_mode=abi.SHARD_TILES, shard_rank=t_rank, shard_count=t_world,
-                     framebuffer_ptr=fb.data_ptr())
-    # this rank's launches: (first_frame, n_frames)
+    r = api.Renderer(packed, device=local, flags=overlap, framebuffer_ptr=fb.data_ptr(), **shard)
+    # this rank's launches of one job: (first_frame, n_frames)
     if by_tiles:
-        launches = [(k * F, F) for k in range(K)]
+        launches = [(f0, min(F, SPP - f0)) for f0 in range(0, SPP, F)]
     else:
-        lo, hi = rdist.frame_block(rank, world, K * F)
+        lo, hi = rdist.frame_block(rank, world, SPP)
         launches = [(f0, min(F, hi - f0)) for f0 in range(lo, hi, F)]
         if len(launches) == 1 and launches[0][1] >= 2:
             # a block that fits one launch is rendered as two: the second starts while the first finishes its longest
@@ -146,27 +177,24 @@ def main():
             else:
                 rdist.reduce_framebuffer(fb, dst=0)
 
-    # ---- untimed: algorithmic bytes per ray from the kernel's own counters (same scene, seeds) ----
-    # (counted over this build's BVH4 -- RENE_FLAG_FORCE_BVH -- so that the figure does not depend on
-    # which intersection back end renders the scene: the small-scene item loop tests every item)
-    cf = min(F, 8)
-    with api.Renderer(packed, device=local, flags=abi.FLAG_COUNTERS | abi.FLAG_FORCE_BVH, shard_mode=abi.SHARD_TILES,
-                      shard_rank=t_rank, shard_count=t_world) as rc:
-        rc.render(0, cf)
-        cst = rc.stats()
-    bytes_per_ray = abi.algorithmic_bytes(cst) / max(1, cst.rays)
+    def job():
+        """One whole job: clear, render every frame of this rank's share, wait, exchange."""
+        r.reset()
+        for f0, nf in launches:
+            r.render(f0, nf)
+        r.sync()
+        exchange()
+        if world > 1:
+            torch.cuda.synchronize()
 
-    # ---- untimed: work-item granularity for launches of F frames (rene_tune; no bit of the image depends on it) ----
+    # ---- untimed: algorithmic bytes per ray, work-item granularity (rene_tune; no bit of the image depends on it) ----
+    bytes_per_ray = algorithmic_bytes_per_ray(packed, api, abi, local, frames=min(F, 8) if head == "cornell" else 2, **shard)
     r.tune(max(nf for _, nf in launches))
 
-    # ---- warmup (kernel + the collective: RCCL sets its rings up lazily), then a clean image ----
-    for k in range(Wm):
-        r.render(k * F, F)
-    r.sync()
-    exchange()
+    # ---- warmup (kernel + the collective: RCCL sets its rings up lazily) ----
+    for _ in range(Wm):
+        job()
     torch.cuda.synchronize()
-    r.reset()
-    fb.zero_()
 
     def fence():
         torch.cuda.synchronize()
@@ -174,18 +202,28 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    step_ms, first_image, identical = [], None, True
+    kernel_ms, n_launches, rays_job = 0.0, 0, 0
     fence()
     t0 = time.perf_counter()
-    for f0, nf in launches:
-        r.render(f0, nf)
-    r.sync()
-    render_s = time.perf_counter() - t0
-    exchange()  # the one exchange step (RCCL over xGMI)
+    for k in range(K):
+        t1 = time.perf_counter()
+        job()
+        step_ms.append((time.perf_counter() - t1) * 1e3)
+        if k == 0 or k == K - 1:  # bookkeeping of the first and last job only: a few host-side reads, no device work
+            st = r.stats()
+            kernel_ms, n_launches, rays_job = st.kernel_ms, st.launches, st.rays
     fence()
     elapsed = time.perf_counter() - t0
 
-    st = r.stats()
-    rays = torch.tensor([float(st.rays)], dtype=torch.float64, device=f"cuda:{local}")
+    # every job renders the same frames: the last image equals a fresh render of the job, bit for bit (one GPU; with
+    # N > 1 the exchange changes rank 0's image in place, compared there as well: the reduce is deterministic)
+    last = fb.clone()
+    job()
+    torch.cuda.synchronize()
+    identical = bool(torch.equal(last[..., :3], fb[..., :3]))
+
+    rays = torch.tensor([float(rays_job) * K], dtype=torch.float64, device=f"cuda:{local}")
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
     if world > 1:
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
@@ -195,44 +233,76 @@ def main():
     if rank == 0:
         img = fb[0, :, :, :3]
         assert bool(torch.isfinite(img).all()) and float(img.mean()) > 0.0, "framebuffer is empty or non-finite"
-        spp = K * F
-        launch_ms = st.kernel_ms / max(1, st.launches)  # HIP events around each launch, on the launch's stream
-        # with RENE_FLAG_OVERLAP two launches are in flight at a time: one launch *lasts* about two launch periods
-        # (it waits for the previous launch's waves to retire before its own become resident), so the share of the
-        # chip's issue cycles in use is priced on the period, not on the duration
-        period_ms = render_s * 1e3 / max(1, st.launches)
-        alg_bytes_per_launch = bytes_per_ray * st.rays / max(1, st.launches)
-        achieved = alg_bytes_per_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+        assert identical, "two renders of the same job differ"
         prop = torch.cuda.get_device_properties(local)
-        valu = valu_issue(F, n_gpus, period_ms, prop.multi_processor_count, 2.4)  # 2.4 GHz: MI355X peak engine clock
-        if valu:
-            valu["lane_ops_per_ray"] = valu["valu_wave_insts_per_launch"] * 64.0 / max(1.0, st.rays / max(1, st.launches))
+        cus = prop.multi_processor_count
+        rate = total_rays / elapsed
+        launch_ms = kernel_ms / max(1, n_launches)  # HIP events around each launch of one job, on the launch's stream
+        period_ms = statistics.median(step_ms) / max(1, len(launches))
+        rl = rooflines(head, rate / n_gpus, cus, bytes_per_ray)
+        rec = pmc_per_ray(head) or {}
+        rays_per_launch = rays_job / max(1, n_launches)
+        traffic = ((rec["hbm_read_bytes_per_ray"] + rec["hbm_write_bytes_per_ray"]) * rays_per_launch
+                   if rec.get("hbm_read_bytes_per_ray") is not None else None)
+        valu = rl["valu"] or {"achieved": None, "peak": cus * SIMDS_PER_CU * LANES_PER_SIMD_CYCLE * CLOCK_GHZ / 1e3, "unit": "Tlane-op/s", "frac": None}
         out = {
-            "metric": "Mrays/s", "value": total_rays / elapsed / 1e6, "unit": "Mrays/s",
+            "metric": "Mrays/s", "value": rate / 1e6, "unit": "Mrays/s",
             "n_gpus": n_gpus, "steps": K, "warmup": Wm, "ms_per_step": elapsed / K * 1e3,
-            "ms_per_frame": elapsed / spp * 1e3,
+            "step_ms_median": statistics.median(step_ms), "step_ms_min": min(step_ms),
+            "ms_per_frame": elapsed / (K * SPP) * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"cornell-box {WIDTH}x{HEIGHT} @ {spp} spp", "width": WIDTH, "height": HEIGHT,
-                       "spp": spp, "frames_per_step": F, "triangles": scene.n_triangles,
+            "config": {"workload": label, "width": WIDTH, "height": HEIGHT,
+                       "spp": SPP, "frames_per_launch": F, "launches_per_step": len(launches), "triangles": scene.n_triangles,
+                       "step": "one whole job: clear the image, render every frame, wait for the last launch" + (", exchange" if world > 1 else ""),
                        "sharding": (f"32x32 tiles round-robin over {n_gpus} GPU(s) + RCCL gather of owned tiles" if by_tiles else
-                                    f"{K * F} frames in {n_gpus} contiguous block(s), one per GPU, + RCCL reduce of the partial images"),
+                                    f"{SPP} frames in {n_gpus} contiguous block(s), one per GPU, + RCCL reduce of the partial images"),
                        "seed": abi.DEFAULT_SEED},
-            "rays": total_rays, "rays_per_path": total_rays / (WIDTH * HEIGHT * spp),
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(F, n_gpus),
-                         "kernel": "render_kernel", "launch_ms": launch_ms,
+            "rays": total_rays, "rays_per_path": total_rays / (WIDTH * HEIGHT * SPP * K),
+            "jobs_bit_identical": identical,
+            "roofline": {"bound": "valu", "achieved": valu["achieved"], "peak": valu["peak"], "unit": valu["unit"],
+                         "frac": valu["frac"], "traffic": traffic,
+                         "kernel": rec.get("kernel", "render_kernel"), "launch_ms": launch_ms,
                          "launch_period_ms": period_ms, "launches_in_flight": 2 if overlap else 1,
-                         "achieved_per_period": alg_bytes_per_launch / (period_ms * 1e-3) / 1e9 if period_ms > 0 else 0.0,
-                         "algorithmic_bytes_per_ray": bytes_per_ray,
-                         "algorithmic_bytes_per_launch": alg_bytes_per_launch,
-                         "valu": valu,
-                         "note": "cache-less model (SURVEY 8d); the 36-triangle scene is cache resident, "
-                                 "so real HBM traffic (`traffic`) is far below it: the kernel is VALU/latency bound. "
-                                 "`achieved` = algorithmic bytes per launch / `launch_ms` (event duration of one launch, what "
-                                 "rocprofv3 reports per dispatch); consecutive launches overlap on two streams, so a launch "
-                                 "completes every `launch_period_ms` and `achieved_per_period` is the rate the chip sustains"},
+                         "valu": rl["valu"], "hbm": rl["hbm"],
+                         "note": "the scene is cache resident: VALU issue is the roof that binds, priced at 2 cycles per wave64 "
+                                 "VALU instruction on a SIMD-32 (transcendentals 4), nominal 2.4 GHz; rates are the sustained ones "
+                                 "(rays of the timed jobs / elapsed) -- with two launches in flight one launch lasts `launch_ms` "
+                                 "(HIP events; what rocprofv3 reports per dispatch) but one completes every `launch_period_ms`; "
+                                 "`hbm.frac` is measured HBM traffic (PMC) against 8 TB/s"},
         }
+        # ---- the other configurations, one full job each (N = 1 only) ----
+        if n_gpus == 1 and not args.no_configs and not args.only:
+            out["configs"] = {}
+            r.close()
+            del fb
+            for name, (lab, mk, spp, fpl) in cfgs.items():
+                if name == head:
+                    continue
+                sc = mk()
+                pk = sc.to_desc()
+                bpr = algorithmic_bytes_per_ray(pk, api, abi, local, frames=2)
+                with api.Renderer(pk, device=local, flags=overlap) as rr:
+                    rr.tune(fpl)
+                    rr.render(0, fpl)
+                    rr.sync()
+                    rr.reset()
+                    t1 = time.perf_counter()
+                    for f0 in range(0, spp, fpl):
+                        rr.render(f0, min(fpl, spp - f0))
+                    rr.sync()
+                    dt = time.perf_counter() - t1
+                    s2 = rr.stats()
+                    im = rr.download(0)
+                assert bool(np.isfinite(im).all()) and float(im.mean()) > 0.0, f"{name}: image empty or non-finite"
+                rl2 = rooflines(name, s2.rays / dt, cus, bpr)
+                out["configs"][name] = {
+                    "workload": lab, "width": pk.xres, "height": pk.yres, "spp": spp, "frames_per_launch": fpl,
+                    "triangles": sc.n_triangles, "rays": s2.rays, "rays_per_path": s2.rays / max(1, s2.paths),
+                    "value": s2.rays / dt / 1e6, "unit": "Mrays/s", "seconds": dt, "ms_per_frame": dt / spp * 1e3,
+                    "launch_ms": s2.kernel_ms / max(1, s2.launches), "launch_period_ms": dt * 1e3 / max(1, s2.launches),
+                    "kernel": (pmc_per_ray(name) or {}).get("kernel"),
+                    "valu": rl2["valu"], "hbm": rl2["hbm"]}
         if n_gpus == 1 and not args.no_cpu_baseline:
             from oracle import oracle  # CPU checker used here only as the reported baseline
             o = oracle.Oracle(packed)
@@ -248,7 +318,10 @@ def main():
                 "algorithmic_bytes_per_ray": abi.algorithmic_bytes(so) / max(1, so.rays),
             }
         print(json.dumps(out), flush=True)
-    r.close()
+    try:
+        r.close()
+    except Exception:
+        pass
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

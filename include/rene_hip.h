@@ -36,7 +36,7 @@ typedef enum rene_status {
   RENE_ERR_INVALID_ARGUMENT = -1,
   RENE_ERR_INVALID_SCENE = -2,
   RENE_ERR_DEVICE = -3,          /* a HIP call failed; message carries hipGetErrorString */
-  RENE_ERR_UNSUPPORTED = -4,     /* e.g. Shape "loopsubdiv", blackbody colours, JPEG / EXR textures */
+  RENE_ERR_UNSUPPORTED = -4,     /* e.g. GIF / TIFF / WebP textures, tiled or DWA-compressed EXR files */
   RENE_ERR_OUT_OF_MEMORY = -5,
   RENE_ERR_IO = -6,
   RENE_ERR_PARSE = -7

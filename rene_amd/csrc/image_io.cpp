@@ -36,7 +36,7 @@ struct Reader {
   bool ok = true;
   Reader(const std::string& s) : p(reinterpret_cast<const unsigned char*>(s.data())), n(s.size()) {}
   bool need(size_t k) {
-    if (at + k > n) ok = false;
+    if (k > n || at > n - k) ok = false;  // no wrap-around for offsets taken from the file
     return ok;
   }
   uint32_t u8() { return need(1) ? p[at++] : 0u; }
@@ -193,13 +193,18 @@ bool decode_bmp(const std::string& data, uint32_t& w, uint32_t& h, std::vector<u
   }
   const size_t stride = (((size_t)w * bpp + 31) / 32) * 4;
   if ((size_t)off_bits + stride * h > data.size()) { err = "truncated pixel data"; return false; }
+  // channel masks must be contiguous runs of bits (0 = channel absent); shift + width never exceeds 32
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t m = mask[k];
+    if (m != 0) {
+      const uint32_t low = m & (~m + 1u), run = m + low;  // adding the lowest set bit clears a contiguous run
+      if ((run & m) != 0) { err = "non-contiguous channel mask"; return false; }
+    }
+  }
   auto field = [](uint32_t v, uint32_t m) -> unsigned char {
     if (m == 0) return 255;
-    int shift = 0;
-    while (!((m >> shift) & 1u)) shift++;
-    uint32_t width = 0;
-    while ((m >> (shift + width)) & 1u) width++;
-    uint32_t x = (v & m) >> shift;
+    const int shift = __builtin_ctz(m), width = __builtin_popcount(m);
+    const uint32_t x = (v & m) >> shift;
     return (unsigned char)(width >= 8 ? x >> (width - 8) : (x * 255u) / ((1u << width) - 1u));
   };
   rgba.resize((size_t)w * h * 4);
@@ -583,6 +588,7 @@ bool decode_exr(const std::string& data, uint32_t& w, uint32_t& h, std::vector<f
   rgba.assign((size_t)w * h * 4, 0.0f);
   std::vector<unsigned char> raw, tmp;
   for (uint32_t b = 0; b < n_blocks; ++b) {
+    if (offsets[b] >= data.size()) { err = "block offset outside the file"; return false; }
     r.at = (size_t)offsets[b];
     const int32_t y0 = (int32_t)r.u32();
     const uint32_t n_src = r.u32();

@@ -221,10 +221,9 @@ int main(int argc, char** argv) {
   double kernel_ms = 0.0;
   for (uint32_t g = 0; g < gpus; ++g) {
     rene_stats st;
-    if (rene_get_stats(ctx[g], &st) == RENE_OK) {
-      rays += st.rays_closest + st.rays_shadow + st.rays_emitter;
-      kernel_ms = std::max(kernel_ms, st.kernel_ms);
-    }
+    if (rene_get_stats(ctx[g], &st) != RENE_OK) return die("rene_get_stats");  // e.g. a hand-off timed out: no image is written
+    rays += st.rays_closest + st.rays_shadow + st.rays_emitter;
+    kernel_ms = std::max(kernel_ms, st.kernel_ms);
   }
   std::vector<float> img;
   std::vector<uint8_t> rgb(n_px * 3);

@@ -127,6 +127,7 @@ struct rene_ctx {
   std::deque<Pending> pending;
   uint64_t frames = 0, launches = 0, owned_pixels = 0, paths = 0;
   double kernel_ms = 0.0, last_ms = 0.0;
+  bool handoff_failed = false;
   // seed schedule cache: seeds[k] = k-th next_u32 of PCG32si::new(master)
 
   template <class T>
@@ -173,6 +174,7 @@ struct rene_ctx {
   int drain() {  // wait for the stream(s) and fold finished launches into the timing totals
     HIP_TRY(hipStreamSynchronize(stream));
     if (stream2) HIP_TRY(hipStreamSynchronize(stream2));
+    const bool had_launches = !pending.empty();
     while (!pending.empty()) {
       Pending& p = pending.front();
       float ms = 0.0f;
@@ -184,9 +186,29 @@ struct rene_ctx {
       hipFree(p.d_seeds);
       pending.pop_front();
     }
+    // a work-item hand-off that gave up (device_code.inc, `give_up`) took the sums as they were: the image is wrong, and
+    // every call that hands results to the caller (rene_sync, rene_download, rene_get_stats, rene_reduce) must say so
+    if (had_launches && d_counters && !handoff_failed) {
+      unsigned long long timeouts = 0;
+      HIP_TRY(hipMemcpy(&timeouts, d_counters + 8, sizeof(timeouts), hipMemcpyDeviceToHost));
+      handoff_failed = timeouts != 0;
+    }
+    if (handoff_failed) return fail(RENE_ERR_DEVICE, "a work-item hand-off timed out inside the render kernel (results invalid; rene_reset clears the condition)");
     return RENE_OK;
   }
 };
+
+// No exception crosses the C boundary: the entry points that allocate host memory run under this guard.
+template <class F>
+static int guarded(F&& f) {
+  try {
+    return f();
+  } catch (const std::bad_alloc&) {
+    return fail(RENE_ERR_OUT_OF_MEMORY, "host allocation failed");
+  } catch (const std::exception& e) {
+    return fail(RENE_ERR_DEVICE, std::string("unexpected exception: ") + e.what());
+  }
+}
 
 extern "C" {
 
@@ -199,7 +221,7 @@ void rene_frame_seeds(uint32_t master_seed, uint32_t first_frame, uint32_t n, ui
   for (uint32_t k = 0; k < n; ++k) out[k] = g.next();
 }
 
-int rene_scene_pack_info(const rene_scene_desc* scene, rene_pack_info* out) {
+static int rene_scene_pack_info_impl(const rene_scene_desc* scene, rene_pack_info* out) {
   if (!scene || !out) return fail(RENE_ERR_INVALID_ARGUMENT, "rene_scene_pack_info: NULL argument");
   rene::PackedScene ps;
   std::string err;
@@ -231,7 +253,7 @@ int rene_scene_pack_info(const rene_scene_desc* scene, rene_pack_info* out) {
   return RENE_OK;
 }
 
-int rene_create(const rene_scene_desc* scene, const rene_opts* opts, rene_ctx** out) {
+static int rene_create_impl(const rene_scene_desc* scene, const rene_opts* opts, rene_ctx** out) {
   if (!scene || !out) return fail(RENE_ERR_INVALID_ARGUMENT, "rene_create: NULL argument");
   *out = nullptr;
   rene_opts o{};
@@ -357,6 +379,9 @@ int rene_create(const rene_scene_desc* scene, const rene_opts* opts, rene_ctx** 
     tile_count = o.shard_count;
   }
   uint32_t owned = c->n_tiles > tile_rank ? (c->n_tiles - tile_rank + tile_count - 1) / tile_count : 0;
+  // work ids are 32-bit: id = level * n_work + slot with up to 31 levels, and udiv_small needs ids below 2^31
+  if ((uint64_t)owned * RENE_TILE_SIZE * RENE_TILE_SIZE * 32ull >= (1ull << 31))
+    return fail(RENE_ERR_UNSUPPORTED, "image too large: more than 2^26 pixels per GPU (shard it by tiles)");
   c->n_work = owned * RENE_TILE_SIZE * RENE_TILE_SIZE;
   // pixels of the image inside the owned tiles: paths per rendered frame (the kernels do not count what the host knows)
   c->owned_pixels = 0;
@@ -449,7 +474,7 @@ void rene_destroy(rene_ctx* c) {
   delete c;
 }
 
-int rene_render(rene_ctx* c, uint32_t first_frame, uint32_t n_frames) {
+static int rene_render_impl(rene_ctx* c, uint32_t first_frame, uint32_t n_frames) {
   if (!c) return fail(RENE_ERR_INVALID_ARGUMENT, "rene_render: NULL context");
   if (n_frames == 0) return RENE_OK;
   if ((uint64_t)first_frame + n_frames > 0xffffffffull) return fail(RENE_ERR_INVALID_ARGUMENT, "frame range overflows u32");
@@ -533,6 +558,7 @@ int rene_render(rene_ctx* c, uint32_t first_frame, uint32_t n_frames) {
     c->epoch = 0;
     P.prev_final = 0;
   }
+  const uint32_t saved_epoch = c->epoch, saved_prev_final = c->prev_final;
   P.epoch = ++c->epoch;
   c->prev_final = (P.epoch << 5) | P.n_levels;
   // swept with the BVH4 (tools/dev_sweep4.py): dragon-class (Matte) peaks at 24 / 12 (4.96 Grays/s; 20 / 16 gave 4.6);
@@ -589,8 +615,13 @@ int rene_render(rene_ctx* c, uint32_t first_frame, uint32_t n_frames) {
   pend.epoch = P.epoch;
   pend.waves = std::min(rene::g_launched_blocks * (uint32_t)(rene::render_block_size() / 64), c->resident_words);
   c->pending.push_back(pend);
+  if (e != hipSuccess) {
+    // nothing was launched: the next launch must not wait for versions this one would have written
+    c->epoch = saved_epoch;
+    c->prev_final = saved_prev_final;
+    return fail(RENE_ERR_DEVICE, std::string("render launch: ") + hipGetErrorString(e));
+  }
   c->launches++;
-  if (e != hipSuccess) return fail(RENE_ERR_DEVICE, std::string("render launch: ") + hipGetErrorString(e));
   if (c->pending.size() > 64) return c->drain();
   return RENE_OK;
 }
@@ -605,7 +636,8 @@ int rene_reset(rene_ctx* c) {
   if (!c) return fail(RENE_ERR_INVALID_ARGUMENT, "rene_reset: NULL context");
   HIP_TRY(hipSetDevice(c->device));
   int rc = c->drain();
-  if (rc != RENE_OK) return rc;
+  if (rc != RENE_OK && !c->handoff_failed) return rc;
+  c->handoff_failed = false;  // the counters are cleared below and the image starts again from zero
   HIP_TRY(hipMemsetAsync(c->fb, 0, c->fb_floats * sizeof(float), c->stream));
   HIP_TRY(hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream));
   HIP_TRY(hipMemsetAsync(c->d_item_done, 0, std::max<size_t>(1, c->n_work) * sizeof(uint32_t), c->stream));
@@ -660,7 +692,7 @@ int rene_framebuffer(rene_ctx* c, void** device_ptr, size_t* n_floats) {
   return RENE_OK;
 }
 
-int rene_download(rene_ctx* c, int layer, int channels, float* dst, size_t dst_floats) {
+static int rene_download_impl(rene_ctx* c, int layer, int channels, float* dst, size_t dst_floats) {
   if (!c || !dst) return fail(RENE_ERR_INVALID_ARGUMENT, "rene_download: NULL argument");
   if (layer < 0 || layer >= RENE_LAYER_COUNT) return fail(RENE_ERR_INVALID_ARGUMENT, "layer out of range");
   if (channels != 3 && channels != 4) return fail(RENE_ERR_INVALID_ARGUMENT, "channels must be 3 or 4");
@@ -692,7 +724,6 @@ int rene_get_stats(rene_ctx* c, rene_stats* out) {
   if (rc != RENE_OK) return rc;
   unsigned long long h[9];
   HIP_TRY(hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
-  if (h[8] != 0) return fail(RENE_ERR_DEVICE, "a work-item hand-off timed out inside the render kernel (results invalid)");
   std::memset(out, 0, sizeof(*out));
   out->rays_closest = h[0];
   out->rays_shadow = h[1];
@@ -814,4 +845,8 @@ void rene_to_aov8(const float* sums, size_t n_floats, uint32_t n_samples, int is
   }
 }
 
+int rene_scene_pack_info(const rene_scene_desc* scene, rene_pack_info* out) { return guarded([&] { return rene_scene_pack_info_impl(scene, out); }); }
+int rene_create(const rene_scene_desc* scene, const rene_opts* opts, rene_ctx** out) { return guarded([&] { return rene_create_impl(scene, opts, out); }); }
+int rene_render(rene_ctx* c, uint32_t first_frame, uint32_t n_frames) { return guarded([&] { return rene_render_impl(c, first_frame, n_frames); }); }
+int rene_download(rene_ctx* c, int layer, int channels, float* dst, size_t dst_floats) { return guarded([&] { return rene_download_impl(c, layer, channels, dst, dst_floats); }); }
 }  // extern "C"

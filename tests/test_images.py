@@ -141,6 +141,31 @@ def test_bmp(tmp_path, hip_lib, bpp, bitfields):
         np.testing.assert_allclose(got.reshape(9, 14, 4), expect_ldr(want), rtol=5e-7, atol=0)
 
 
+def test_bmp_hostile_masks(tmp_path, hip_lib):
+    """a full-width mask used to spin for ever (shift + width = 32), a mask with holes has no meaning, and
+    a block offset near 2^64 used to wrap the bounds check of the EXR reader."""
+    img = _picture(2, 2, 4)
+    good = bmp_bytes(img, 32, bitfields=True)
+    at = good.index(struct.pack("<IIII", 0x0000ff00, 0x00ff0000, 0xff000000, 0x000000ff))
+    full = good[:at] + struct.pack("<IIII", 0xffffffff, 0x00ff0000, 0xff000000, 0) + good[at + 16:]
+    (tmp_path / "full.bmp").write_bytes(full)
+    got = load(tmp_path, "full.bmp").reshape(2, 2, 4)  # returns (the top byte of the whole pixel word as red), does not hang
+    assert np.isfinite(got).all()
+    holes = good[:at] + struct.pack("<IIII", 0x00ff00ff, 0x00ff0000, 0xff000000, 0) + good[at + 16:]
+    (tmp_path / "holes.bmp").write_bytes(holes)
+    with pytest.raises(api.ReneError) as e:
+        load(tmp_path, "holes.bmp")
+    assert e.value.code == -6 and "non-contiguous" in str(e.value)
+    exr = exr_bytes({"R": (np.zeros((4, 4), np.float16), "half"), "G": (np.zeros((4, 4), np.float16), "half"), "B": (np.zeros((4, 4), np.float16), "half")}, 4, 4, 0)
+    # the offset table (4 blocks: one line each without compression) follows the header: its first entry points just past itself
+    table = next(p for p in range(len(exr) - 8) if struct.unpack("<Q", exr[p:p + 8])[0] == p + 32)
+    bad = exr[:table] + struct.pack("<Q", 2 ** 64 - 4) + exr[table + 8:]
+    (tmp_path / "wrap.exr").write_bytes(bad)
+    with pytest.raises(api.ReneError) as e:
+        load(tmp_path, "wrap.exr")
+    assert e.value.code == -6 and "offset" in str(e.value)
+
+
 # ------------------------------------------------------------------------------------------------ EXR
 def _attr(name, typ, value):
     return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<i", len(value)) + value

@@ -1,0 +1,116 @@
+#!/usr/bin/env python3
+"""Developer measurements on a GPU box (one script; `gpurun -- python3 tools/dev.py <command> ...`).
+
+  rate NAME... [--frames F] [--launches N] [--serial] [--no-tune]   wall-clock Mrays/s of bench.py's configurations
+        (plus zoo, fog, media-zoo, veach-bvh, cornell-bvh), launches overlapped unless --serial
+  sweep VAR V1,V2,... NAME [rate options]                           the same once per value of an environment knob
+        (RENE_LEVELS, RENE_READY_MIN, RENE_LEAF_MIN, RENE_BLOCKS_PER_CU, ...): fresh process per value
+  soak                                                               C4 / C5 at their full sample counts: no hand-off may time out
+  counters NAME...                                                   per-ray node / primitive / hit counters of the counting pass
+"""
+import argparse
+import os
+import subprocess
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def scene_table():
+    from rene_amd import abi, scenes
+
+    def vol_cornell():
+        s = scenes.cornell_box(1024, 1024)
+        s.integrator = abi.INTEGRATOR_VOLPATH
+        return s
+    return {
+        "cornell": (lambda: scenes.cornell_box(1024, 1024), 256, 0),
+        "veach-mis": (lambda: scenes.veach_mis(1024, 1024), 256, 0),
+        "dragon-class": (lambda: scenes.dragon_class(1920, 1080), 64, 0),
+        "teapot-class": (lambda: scenes.teapot_class(1920, 1080), 128, 0),
+        "zoo": (lambda: scenes.material_zoo(1024, 768), 32, 0),
+        "fog": (lambda: scenes.cornell_fog(1024, 1024), 16, 0),
+        "media-zoo": (lambda: scenes.media_zoo(1024, 768), 16, 0),
+        "cornell-vol": (vol_cornell, 32, 0),
+        "cornell-bvh": (lambda: scenes.cornell_box(1024, 1024), 64, abi.FLAG_FORCE_BVH),
+        "veach-bvh": (lambda: scenes.veach_mis(1024, 1024), 64, abi.FLAG_FORCE_BVH),
+    }
+
+
+def rate(names, frames, launches, serial, tune, extra_flags=0):
+    from rene_amd import abi, api
+    tab = scene_table()
+    for nm in names:
+        mk, F, fl = tab[nm]
+        F = frames or F
+        s = mk()
+        flags = fl | extra_flags | (0 if serial else abi.FLAG_OVERLAP)
+        with api.Renderer(s, flags=flags) as r:
+            if tune:
+                r.tune(F)
+            r.render(0, min(F, 4))
+            r.sync()
+            r.reset()
+            t0 = time.perf_counter()
+            for k in range(launches):
+                r.render(k * F, F)
+            r.sync()
+            wall = time.perf_counter() - t0
+            st = r.stats()
+        print(f"{nm}: {st.rays / wall / 1e6:.0f} Mrays/s wall ({'serial' if serial else 'overlapped'}, {launches} x {F} frames, "
+              f"{wall * 1e3 / launches:.2f} ms/launch wall, {st.kernel_ms / st.launches:.2f} ms events), {wall * 1e3 / st.frames:.4f} ms/frame, "
+              f"rays/path {st.rays / st.paths:.2f}", flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("command")
+    ap.add_argument("args", nargs="*")
+    ap.add_argument("--frames", type=int, default=0)
+    ap.add_argument("--launches", type=int, default=6)
+    ap.add_argument("--serial", action="store_true")
+    ap.add_argument("--no-tune", action="store_true")
+    ap.add_argument("--flags", type=lambda v: int(v, 0), default=0)
+    a = ap.parse_args()
+    if a.command == "rate":
+        rate(a.args or ["cornell", "veach-mis", "dragon-class", "teapot-class"], a.frames, a.launches, a.serial, not a.no_tune, a.flags)
+    elif a.command == "sweep":
+        var, values, names = a.args[0], a.args[1].split(","), a.args[2:]
+        for v in values:
+            env = dict(os.environ, **{var: v})
+            cmd = [sys.executable, os.path.abspath(__file__), "rate", *names, "--launches", str(a.launches), "--frames", str(a.frames), "--flags", str(a.flags)]
+            cmd += (["--serial"] if a.serial else []) + (["--no-tune"] if a.no_tune else [])
+            p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+            print(f"{var}={v}: " + " | ".join(l for l in p.stdout.splitlines() if l) + (p.stderr[-300:] if p.returncode else ""), flush=True)
+    elif a.command == "soak":
+        import numpy as np
+        from rene_amd import abi, api, scenes
+        for nm, s, spp, F in (("dragon-class 1920x1080 @ 1024 spp", scenes.dragon_class(1920, 1080), 1024, 64),
+                              ("teapot-class 1920x1080 @ 8192 spp", scenes.teapot_class(1920, 1080), 8192, 128)):
+            with api.Renderer(s, flags=abi.FLAG_OVERLAP) as r:
+                r.tune(F)
+                t0 = time.perf_counter()
+                for f in range(0, spp, F):
+                    r.render(f, F)
+                r.sync()
+                dt = time.perf_counter() - t0
+                st = r.stats()  # raises if a hand-off timed out
+                img = r.download(0)
+            print(f"{nm}: {dt:.2f} s, {st.rays / dt / 1e6:.0f} Mrays/s, {dt * 1e3 / spp:.3f} ms/frame, finite {bool(np.isfinite(img).all())}, mean {img.mean() / spp:.4f}", flush=True)
+    elif a.command == "counters":
+        from rene_amd import abi, api
+        tab = scene_table()
+        for nm in a.args:
+            mk, F, fl = tab[nm]
+            with api.Renderer(mk(), flags=fl | abi.FLAG_COUNTERS) as rc:
+                rc.render(0, 2)
+                c = rc.stats().as_dict()
+            print(nm, {k: round(c[k] / c["rays"], 3) for k in ("node_visits", "prim_tests", "hits", "adds", "rays_closest", "rays_shadow", "rays_emitter")},
+                  "B_alg/ray", round(abi.algorithmic_bytes(c) / c["rays"], 1), flush=True)
+    else:
+        raise SystemExit(__doc__)
+
+
+if __name__ == "__main__":
+    main()
