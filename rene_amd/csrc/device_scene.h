@@ -150,6 +150,24 @@ constexpr float SMALL_KIND_QUAD = 0.0f, SMALL_KIND_TRIANGLE = 1.0f, SMALL_KIND_S
 //   q[2f+1] = bits(sel_s | flip_s << 2 | sel_r << 3 | flip_r << 5)   the face's own (s, r) from the two in-face box
 //             coordinates (ascending axis order): s = flip_s ? 1 - coord[sel_s] : coord[sel_s], likewise r
 
+// ---- small scenes: the tables the shading steps read, resident in LDS --------------------------------------------
+// A FEAT_SMALL scene carries an *LDS image* (SceneView::small_image, at most SMALL_LDS_MAX_BYTES): every workgroup of a
+// render kernel copies it into its LDS once, when it starts (the launch is persistent), and hit shading, emitter
+// sampling and the emitter pdf read their records from there -- a per-lane ds_read_b128 returns in ~64 cycles where the
+// same gather through L1 / L2 took 200-500, sixteen dependent round trips per bounce (rocprofv3: 39 % of the wave
+// cycles parked on s_waitcnt).  Records are fattened so that one index reaches everything a step needs:
+//   byte 0                   main structure's items + auxiliary records (copy of Accel::items), 64 B each:
+//                            the (item, s, r) -> (slot, u, v) mapping after the item loop
+//   small_off[SMALL_OFF_EMIT_ITEMS]  the emitter structure's items
+//   small_off[SMALL_OFF_HIT]   per main slot, 160 B: PrimIsect (48) | PrimShade (64) | the slot's Inst (48)
+//   small_off[SMALL_OFF_EMIT]  per emitter slot, 80 B: PrimIsect (48) | EmitPdf (16) | primitive_count 0 0 0
+//   small_off[SMALL_OFF_EOBJ]  EmitObject[] (64 B each)
+//   small_off[SMALL_OFF_ETRI]  EmitTri[] (48 B each)
+// A scene whose image would not fit is not FEAT_SMALL (it renders through the BVH kernels).
+constexpr uint32_t SMALL_LDS_MAX_BYTES = 24u * 1024u;  // six workgroups per CU keep their image in 160 KB of LDS
+enum : uint32_t { SMALL_OFF_EMIT_ITEMS = 0, SMALL_OFF_HIT, SMALL_OFF_EMIT, SMALL_OFF_EOBJ, SMALL_OFF_ETRI, SMALL_OFF_COUNT };
+constexpr uint32_t SMALL_HIT_FLOATS = 40, SMALL_EMIT_FLOATS = 20;
+
 // one traversable structure
 struct Accel {
   const Node* nodes;
@@ -193,6 +211,10 @@ struct SceneView {
   uint32_t lights_len;
   uint32_t emit_object_len;
   uint32_t width, height;
+  uint32_t small_bytes;                  // FEAT_SMALL: size of the LDS image (a multiple of 16), else 0
+  const float* small_image;              // FEAT_SMALL: the LDS image in HBM (layout above)
+  uint32_t small_off[SMALL_OFF_COUNT];   // byte offsets of its tables
+  uint32_t pad_;
 };
 
 // scene feature bits -> kernel specialisation

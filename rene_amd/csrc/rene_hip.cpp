@@ -337,7 +337,10 @@ static int rene_create_impl(const rene_scene_desc* scene, const rene_opts* opts,
   UP(ps.inst_medium, v.inst_medium);
   UP(ps.images, v.images);
   UP(ps.image_pool, v.image_pool);
+  UP(ps.small_image, v.small_image);
 #undef UP
+  v.small_bytes = (uint32_t)(ps.small_image.size() * sizeof(float));
+  for (uint32_t k = 0; k < rene::SMALL_OFF_COUNT; ++k) v.small_off[k] = ps.small_off[k];
   {
     std::vector<rene::Uniforms> u(1);
     std::memcpy(u[0].c2w, ps.uniform.camera_to_world, 64);

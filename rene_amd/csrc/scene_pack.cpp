@@ -916,7 +916,37 @@ int pack_scene(const rene_scene_desc* d, PackedScene& out, std::string& err) {
   finish_accel(eprims, max_leaf, out.emit, order);
   out.emit_pdf.resize(eprims.size());
   for (size_t s = 0; s < eprims.size(); ++s) out.emit_pdf[s] = eprims[order[s]].pdf;
-  if (!out.main.items.empty() && (eprims.empty() || !out.emit.items.empty())) out.features |= FEAT_SMALL;
+  if (!out.main.items.empty() && (eprims.empty() || !out.emit.items.empty())) {
+    // the LDS image of the small-scene kernels (device_scene.h): items for the hit mapping, one fat record per slot
+    std::vector<float>& img = out.small_image;
+    auto append = [&](const float* p, size_t n) { img.insert(img.end(), p, p + n); };
+    auto bits = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+    for (const SmallItem& it : out.main.items) append(it.q, 16);
+    out.small_off[SMALL_OFF_EMIT_ITEMS] = (uint32_t)(img.size() * 4);
+    for (const SmallItem& it : out.emit.items) append(it.q, 16);
+    out.small_off[SMALL_OFF_HIT] = (uint32_t)(img.size() * 4);
+    for (size_t s = 0; s < out.main.isect.size(); ++s) {
+      append(out.main.isect[s].q, 12);
+      append(out.shade[s].q, 16);
+      const Inst& in = out.insts[bits(out.main.isect[s].q[9])];
+      static_assert(sizeof(Inst) == 48, "Inst is three float4");
+      append(reinterpret_cast<const float*>(&in), 12);
+    }
+    out.small_off[SMALL_OFF_EMIT] = (uint32_t)(img.size() * 4);
+    for (size_t s = 0; s < out.emit.isect.size(); ++s) {
+      append(out.emit.isect[s].q, 12);
+      append(out.emit_pdf[s].q, 4);
+      const float tail[4] = {out.insts[bits(out.emit.isect[s].q[9])].primitive_count, 0.f, 0.f, 0.f};
+      append(tail, 4);
+    }
+    out.small_off[SMALL_OFF_EOBJ] = (uint32_t)(img.size() * 4);
+    static_assert(sizeof(EmitObject) == 64 && sizeof(EmitTri) == 48, "LDS image record sizes");
+    for (const EmitObject& e : out.emit_objects) append(reinterpret_cast<const float*>(&e), 16);
+    out.small_off[SMALL_OFF_ETRI] = (uint32_t)(img.size() * 4);
+    for (const EmitTri& e : out.emit_tris) append(e.q, 12);
+    if (img.size() * 4 <= SMALL_LDS_MAX_BYTES) out.features |= FEAT_SMALL;
+    else img.clear();  // too many slots for the LDS-resident tables: the BVH kernels render it
+  }
   return RENE_OK;
 }
 

@@ -38,6 +38,8 @@ struct PackedScene {
   uint32_t width = 0, height = 0;
   uint32_t features = 0;
   uint32_t n_triangles = 0;  // world-space triangles after flattening
+  std::vector<float> small_image;              // FEAT_SMALL: the LDS image (device_scene.h)
+  uint32_t small_off[SMALL_OFF_COUNT] = {};
 };
 
 // returns a rene_status; fills err on failure

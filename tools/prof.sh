@@ -6,7 +6,8 @@
 #   fetch  FETCH_SIZE  /  write  WRITE_SIZE             HBM bytes (x2 for reads: gfx950 correction, MI355X_MICROARCH.md)
 #   sq1    instruction mix + lane utilisation           sq2  where the wave cycles go (wait / issue / active), memory instructions
 #   sq3    scalar data cache + L2 hit rate
-# Outputs land in gpurun_out/prof_<TAG>_<NAME>_<pass>/; tools/summarize_profiles.py turns them into profiles/*.
+# Each pass is reduced to gpurun_out/prof_<TAG>_<NAME>_<pass>.json (+ .log) by tools/extract_pass.py;
+# tools/summarize_profiles.py turns those into profiles/*.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 TAG=$1; NAME=$2; STEPS=${3:-2}; PASSES=${4:-"stats fetch write sq1 sq2 sq3"}
@@ -25,5 +26,5 @@ for p in $PASSES; do
   D=$OUT/prof_${TAG}_${NAME}_$p
   rm -rf $D
   timeout -k 10 420 rocprofv3 --kernel-trace $ARGS -d $D -o p -- $CMD > $D.log 2>&1 || { echo "pass $p failed"; tail -5 $D.log; exit 1; }
-  echo "pass $p done: $(grep -c . $D.log) log lines"
+  python3 $R/tools/extract_pass.py $D && rm -rf $D
 done

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turns the rocprofv3 outputs of tools/prof.sh (gpurun_out/prof_<tag>_<name>_<pass>/p_results.db + .log) into the
+"""Turns the rocprofv3 outputs of tools/prof.sh (gpurun_out/prof_<tag>_<name>_<pass>.json + .log) into the
 summaries committed under profiles/:
 
   profiles/<tag>_<name>_kernel_stats.txt   rocprofv3 --kernel-trace --stats: per-kernel calls / total / average
@@ -18,21 +18,18 @@ usage: tools/summarize_profiles.py TAG NAME
 """
 import json
 import os
-import sqlite3
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PASSES = ("fetch", "write", "sq1", "sq2", "sq3")
 
 
-def q(path, sql):
-    if not os.path.exists(path):
-        return []
-    db = sqlite3.connect(path)
+def load_pass(path):
+    """tools/extract_pass.py's reduction of one pass: {"top_kernels": [...], "dispatches": [[kernel, dispatch, counter, sum, duration, ...]]}"""
     try:
-        return list(db.execute(sql))
-    finally:
-        db.close()
+        return json.load(open(path))
+    except Exception:
+        return {"top_kernels": [], "dispatches": []}
 
 
 def bench_line(log):
@@ -53,7 +50,7 @@ def main():
     os.makedirs(out, exist_ok=True)
     base = os.path.join(g, f"prof_{tag}_{name}_")
 
-    rows = q(base + "stats/p_results.db", "select * from top_kernels")
+    rows = load_pass(base + "stats.json")["top_kernels"]
     line = bench_line(base + "stats.log")
     cmd = f"python3 bench.py --only {name} --steps {line['steps'] if line else '?'} --warmup 1 --no-cpu-baseline"
     if rows:
@@ -69,11 +66,8 @@ def main():
 
     per_ray, pmc_lines, kernel = {}, [], None
     for p in PASSES:
-        db = base + p + "/p_results.db"
         line_p = bench_line(base + p + ".log")
-        rs = q(db, "select kernel_name, dispatch_id, counter_name, sum(value), max(duration) from counters_collection "
-                   "group by kernel_name, dispatch_id, counter_name order by dispatch_id")
-        rs = [r for r in rs if "rene::" in r[0]]
+        rs = [r[:5] for r in load_pass(base + p + ".json")["dispatches"]]
         if not rs:
             continue
         # dominant kernel = the one with the largest total duration
