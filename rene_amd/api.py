@@ -15,7 +15,8 @@ import numpy as np
 from . import abi
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB_PATH = os.path.join(_CSRC, "librene_hip.so")
+# RENE_HIP_LIB names another build of the same library in csrc/ (A/B measurements of kernel variants, Makefile `variant`)
+LIB_PATH = os.path.join(_CSRC, os.environ.get("RENE_HIP_LIB", "librene_hip.so"))
 _LIB = None
 
 

@@ -5,7 +5,8 @@
 #   stats  --kernel-trace --stats                       per-kernel time
 #   fetch  FETCH_SIZE  /  write  WRITE_SIZE             HBM bytes (x2 for reads: gfx950 correction, MI355X_MICROARCH.md)
 #   sq1    instruction mix + lane utilisation           sq2  where the wave cycles go (wait / issue / active), memory instructions
-#   sq3    scalar data cache + L2 hit rate
+#   sq3    scalar data cache + L2 hit rate            sq4  average latency of scalar / vector / LDS accesses (LEVEL / INSTS), branches
+#   sq5    instruction fetch, per-unit active time    sq6  instruction cache
 # Each pass is reduced to gpurun_out/prof_<TAG>_<NAME>_<pass>.json (+ .log) by tools/extract_pass.py;
 # tools/summarize_profiles.py turns those into profiles/*.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -20,6 +21,9 @@ for p in $PASSES; do
     write) ARGS="--pmc WRITE_SIZE" ;;
     sq1) ARGS="--pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU" ;;
     sq2) ARGS="--pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_INST_LDS" ;;
+    sq4) ARGS="--pmc SQ_INSTS_SMEM SQ_INST_LEVEL_SMEM SQ_INSTS_VMEM SQ_INST_LEVEL_VMEM SQ_INSTS_LDS SQ_INST_LEVEL_LDS SQ_INSTS_BRANCH SQ_WAVE_CYCLES" ;;
+    sq5) ARGS="--pmc SQ_IFETCH SQ_IFETCH_LEVEL SQ_INST_CYCLES_SALU SQ_INST_CYCLES_SMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC" ;;
+    sq6) ARGS="--pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_TC_REQ SQC_TC_STALL" ;;
     sq3) ARGS="--pmc SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE" ;;
     *) echo "unknown pass $p"; exit 2 ;;
   esac

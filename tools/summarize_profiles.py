@@ -21,7 +21,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PASSES = ("fetch", "write", "sq1", "sq2", "sq3")
+PASSES = ("fetch", "write", "sq1", "sq2", "sq3", "sq4", "sq5", "sq6")
 
 
 def load_pass(path):
