@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RENE_ABI_VERSION 2u
+#define RENE_ABI_VERSION 3u
 
 typedef enum rene_status {
   RENE_OK = 0,
@@ -291,7 +291,8 @@ int rene_reset(rene_ctx* ctx);
  * no bit of any image -- a pixel's frames are added in the same order however they are cut. */
 int rene_tune(rene_ctx* ctx, uint32_t n_frames);
 
-/* Device address of the accumulation image [3][yres][xres][4] f32 (for an RCCL reduce by the host). */
+/* Device address of the accumulation image [3][yres][xres][4] f32 (for callers that run their own exchange, e.g.
+ * torch.distributed; rene_reduce / rene_gather_tiles below do it inside the library). */
 int rene_framebuffer(rene_ctx* ctx, void** device_ptr, size_t* n_floats);
 
 int rene_get_stats(rene_ctx* ctx, rene_stats* out);
@@ -318,6 +319,44 @@ int rene_bsdf_eval(rene_ctx* ctx, uint32_t material_index, size_t n, const float
 int rene_medium_eval(rene_ctx* ctx, uint32_t medium_index, size_t n, const float* rd3,
                      const float* t_max, const float* wo3, const float* wi3, const uint32_t* seeds,
                      float* out16);
+
+/* Per-function probe of the emitter-pdf query (rene-shader/src/lib.rs:301-318: trace `direction` from `origin`
+ * against the emitter-only structure, tmin 0.001, tmax 1e5, then main_miss_pdf / triangle_closest_hit_pdf /
+ * sphere_closest_hit_pdf, lib.rs:959-1066): out[i] = pdf_l of ray i (0 on a miss).  Host pointers. */
+int rene_emitter_pdf(rene_ctx* ctx, size_t n, const float* origins, const float* directions, float* out);
+
+/* Probe of the device random stream (PCG32si, rene-shader/src/rand.rs:4-52): out[k] = the k-th next_u32() of
+ * PCG32si::new(seed) computed by one lane of `device`.  Integer-exact known answers: tests/golden/pcg32si_kat.json. */
+int rene_pcg_probe(int device, uint32_t seed, uint32_t n, uint32_t* out);
+
+/* ---- multi-GPU exchange step inside the boundary: RCCL over xGMI ---------------------------------
+ * The reference renders on one GPU; this build shards a job over the GPUs of a node (one context per GPU; tiles or
+ * frame blocks, rene_opts.shard_*) and needs exactly one exchange at the end of a job -- the sum of the per-GPU
+ * accumulation images (SURVEY section 8 e).  These entry points keep it on the device: ncclReduce / ncclSend /
+ * ncclRecv on the context's own stream, ordered after its launches.  RCCL (librccl.so) is loaded when the first of
+ * them is called; RENE_ERR_UNSUPPORTED if it is absent.
+ *   one process per GPU:  rank 0 calls rene_comm_unique_id and hands the 128 bytes to the other ranks by whatever means
+ *                         the host has (a file, a socket, torch.distributed's store); every rank then calls rene_comm_init;
+ *   one process, n GPUs:  rene_comm_init_all over its n contexts (ncclCommInitAll); calls on different contexts of one
+ *                         communicator must then be made from different host threads or inside rene_comm_group_begin /
+ *                         rene_comm_group_end (ncclGroupStart / ncclGroupEnd).
+ * After an exchange the root's image holds the job's sums; every context of the communicator needs rene_reset before
+ * it renders again (the records' version words have been summed or overwritten). */
+#define RENE_COMM_ID_BYTES 128
+int rene_comm_unique_id(uint8_t id[RENE_COMM_ID_BYTES]);
+int rene_comm_init(rene_ctx* ctx, int n_ranks, int rank, const uint8_t id[RENE_COMM_ID_BYTES]);
+int rene_comm_init_all(rene_ctx** ctxs, int n);
+int rene_comm_group_begin(void);
+int rene_comm_group_end(void);
+/* Frame-sharded jobs (RENE_SHARD_FRAMES, or any cut in which several ranks add to the same pixel): sum of the
+ * [3][yres][xres][4] f32 images onto rank `root`, in place (ncclReduce, ncclSum).  Differs from a one-GPU render only
+ * in fp32 summation order. */
+int rene_reduce(rene_ctx* ctx, int root);
+/* Tile-sharded jobs (RENE_SHARD_TILES: every pixel has exactly one owner): every rank sends ONLY the 32x32 tiles it
+ * owns to `root` (1 / n_ranks of the image per rank), which places them; the root's image is then bit-identical to a
+ * one-GPU render.  All contexts of the communicator must have been created with shard_count == n_ranks and
+ * shard_rank == their rank. */
+int rene_gather_tiles(rene_ctx* ctx, int root);
 
 void rene_destroy(rene_ctx* ctx);
 

@@ -42,6 +42,7 @@ def lib():
         for name in ("oracle_trace", "oracle_trace_bruteforce"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p,
                                          C.c_float, C.c_float, C.c_void_p]
+        L.oracle_emitter_pdf.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_last_error.restype = C.c_char_p
         L.oracle_pcg_state_after_new.argtypes = [C.c_uint32, C.POINTER(C.c_uint32)]
         L.oracle_pcg_u32.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
@@ -108,6 +109,15 @@ class Oracle:
         fn = lib().oracle_trace_bruteforce if bruteforce else lib().oracle_trace
         fn(self._h, which, o.shape[0], _p(o), _p(d), tmin, tmax, _p(out))
         return out
+
+    def emitter_pdf(self, origins, directions):
+        """(pdf_l in fp32 as the reference computes it, the sphere formula in fp64) per ray -- lib.rs:301-318, 959-1066."""
+        o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
+        out = np.zeros(o.shape[0], np.float32)
+        out64 = np.zeros(o.shape[0], np.float64)
+        lib().oracle_emitter_pdf(self._h, o.shape[0], _p(o), _p(d), _p(out), _p(out64))
+        return out, out64
 
     def camera_ray(self, s: float, t: float):
         o = np.zeros(3, np.float32)

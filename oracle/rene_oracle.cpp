@@ -1666,6 +1666,31 @@ int oracle_trace(oracle_ctx* c, int which, size_t n, const float* o, const float
   return 0;
 }
 
+// The emitter-pdf query of lib.rs:301-318 for a batch of rays: trace the emitter-only TLAS (tmin 0.001, tmax 1e5),
+// then main_miss_pdf / triangle_closest_hit_pdf / sphere_closest_hit_pdf.  out64 (optional): the sphere formula of
+// lib.rs:1058-1064 evaluated in double from the same fp32 inputs -- what the fp32 expression 1 - sqrt(1 - r^2/d^2)
+// loses to cancellation for a small, distant emitter (0 for triangles and misses).
+int oracle_emitter_pdf(oracle_ctx* c, size_t n, const float* o, const float* d, float* out, double* out64) {
+  Scene& s = c->s;
+  Counters cc;
+  for (size_t i = 0; i < n; ++i) {
+    V3 ro = v3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), rd = v3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+    Hit h = s.trace(s.tlas_emit, s.tlas_emit_inst, ro, rd, 0.001f, 100000.0f, false, cc);
+    out[i] = s.closest_hit_pdf(h, ro, rd);
+    if (out64) {
+      out64[i] = 0.0;
+      if (!h.miss && s.instances[h.instance].shape == RENE_SHAPE_SPHERE) {
+        const Instance& in = s.instances[h.instance];
+        const double radius = ((double)std::fabs(in.o2w.x.x) + (double)std::fabs(in.o2w.y.y) + (double)std::fabs(in.o2w.z.z)) / 3.0;
+        const double dx = (double)in.o2w.w.x - ro.x, dy = (double)in.o2w.w.y - ro.y, dz = (double)in.o2w.w.z - ro.z;
+        const double cos_max = std::sqrt(std::max(1.0 - radius * radius / (dx * dx + dy * dy + dz * dz), 0.0));
+        out64[i] = 1.0 / (2.0 * 3.14159265358979323846 * (1.0 - cos_max));
+      }
+    }
+  }
+  return 0;
+}
+
 // brute force over every primitive, no BVH at all: pins the oracle's own traversal
 int oracle_trace_bruteforce(oracle_ctx* c, int which, size_t n, const float* o, const float* d,
                             float tmin, float tmax, rene_hit* out) {

@@ -62,6 +62,13 @@ def lib():
     L.rene_trace.argtypes = [vp, i32, C.c_size_t, vp, vp, C.c_float, C.c_float, vp]
     L.rene_bsdf_eval.argtypes = [vp, u32, C.c_size_t, vp, vp, vp, vp, vp, vp]
     L.rene_medium_eval.argtypes = [vp, u32, C.c_size_t, vp, vp, vp, vp, vp, vp]
+    L.rene_emitter_pdf.argtypes = [vp, C.c_size_t, vp, vp, vp]
+    L.rene_pcg_probe.argtypes = [i32, u32, u32, vp]
+    L.rene_comm_unique_id.argtypes = [vp]
+    L.rene_comm_init.argtypes = [vp, i32, i32, vp]
+    L.rene_comm_init_all.argtypes = [C.POINTER(vp), i32]
+    L.rene_reduce.argtypes = [vp, i32]
+    L.rene_gather_tiles.argtypes = [vp, i32]
     L.rene_destroy.argtypes = [vp]
     L.rene_scene_pack_info.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(abi.PackInfo)]
     L.rene_destroy.restype = None
@@ -170,6 +177,51 @@ class Renderer:
         _check(lib().rene_trace(self._h, which, o.shape[0], o.ctypes.data_as(C.c_void_p),
                                 d.ctypes.data_as(C.c_void_p), tmin, tmax, out.ctypes.data_as(C.c_void_p)))
         return out
+
+
+def _emitter_pdf(self, origins, directions) -> np.ndarray:
+    """Device emitter-pdf probe (lib.rs:301-318 + 959-1066): pdf_l of each ray against the emitter-only structure."""
+    o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+    d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
+    out = np.zeros(o.shape[0], np.float32)
+    p = lambda x: x.ctypes.data_as(C.c_void_p)
+    _check(lib().rene_emitter_pdf(self._h, o.shape[0], p(o), p(d), p(out)))
+    return out
+
+
+Renderer.emitter_pdf = _emitter_pdf
+
+
+def _comm_init(self, n_ranks: int, rank: int, unique_id: bytes):
+    """Join an RCCL communicator (one context per GPU); `unique_id` = comm_unique_id() of rank 0, handed over by the host."""
+    buf = (C.c_uint8 * abi.COMM_ID_BYTES).from_buffer_copy(unique_id)
+    _check(lib().rene_comm_init(self._h, n_ranks, rank, buf))
+
+
+def _reduce(self, root: int = 0):
+    _check(lib().rene_reduce(self._h, root))
+
+
+def _gather_tiles(self, root: int = 0):
+    _check(lib().rene_gather_tiles(self._h, root))
+
+
+Renderer.comm_init = _comm_init
+Renderer.reduce = _reduce
+Renderer.gather_tiles = _gather_tiles
+
+
+def comm_unique_id() -> bytes:
+    buf = (C.c_uint8 * abi.COMM_ID_BYTES)()
+    _check(lib().rene_comm_unique_id(buf))
+    return bytes(buf)
+
+
+def pcg_probe(seed: int, n: int, device: int = 0) -> np.ndarray:
+    """n outputs of PCG32si::new(seed) computed on the device (rene_pcg_probe)."""
+    out = np.zeros(n, np.uint32)
+    _check(lib().rene_pcg_probe(device, seed & 0xFFFFFFFF, n, out.ctypes.data_as(C.c_void_p)))
+    return out
 
 
 def _bsdf_eval(self, material_index: int, normals, uvs, wo, wi, seeds) -> np.ndarray:

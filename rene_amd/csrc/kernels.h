@@ -46,6 +46,12 @@ hipError_t launch_bsdf_eval(const SceneView& S, uint32_t material, uint32_t n, c
                             const float* wo3, const float* wi3, const uint32_t* seeds, float* out, hipStream_t st);
 hipError_t launch_medium_eval(const SceneView& S, uint32_t medium, uint32_t n, const float* rd3, const float* t_max,
                               const float* wo3, const float* wi3, const uint32_t* seeds, float* out, hipStream_t st);
+hipError_t launch_emitter_pdf(const LaunchConfig& cfg, const SceneView& S, uint32_t n, const float* o, const float* d, float* out, hipStream_t st);
+hipError_t launch_pcg_probe(uint32_t seed, uint32_t n, uint32_t* out, hipStream_t st);
+// tile-sharded exchange: the 32x32 tiles with index % shard_count == shard_rank of a [3][H][W][4] image <-> a packed
+// buffer [owned tile][layer][32][32][4] (out-of-image texels of edge tiles are zero / skipped)
+hipError_t launch_pack_tiles(const float* fb, float* packed, uint32_t width, uint32_t height, uint32_t tiles_x, uint32_t n_tiles,
+                             uint32_t shard_rank, uint32_t shard_count, bool unpack, hipStream_t st);
 int render_block_size();
 
 }  // namespace rene

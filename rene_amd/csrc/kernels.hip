@@ -33,6 +33,68 @@ __global__ void __launch_bounds__(BLOCK) trace_kernel(SceneView S, int which, ui
 }
 
 // -------------------------------------------------------------------------------------------------
+// emitter-pdf probe (rene_emitter_pdf): the query of lib.rs:301-318 for a batch of rays, one lane per ray
+// -------------------------------------------------------------------------------------------------
+template <bool SMALL>
+__global__ void __launch_bounds__(BLOCK) emitter_pdf_kernel(SceneView S, uint32_t n, const float* o3, const float* d3, float* out) {
+  extern __shared__ uint32_t s_stack[];
+  uint32_t* stack = s_stack + threadIdx.x;
+  uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  const bool live = i < n;
+  if (!live) i = n - 1;  // keep the wave converged for the coherent item loop
+  LaneCounters lc;
+  f3 o = mk3(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]), d = mk3(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]);
+  HitRec h = trace_accel<SMALL, false, true, false>(S.emit, S.spheres, o, d, 0.001f, 100000.0f, stack, lc);
+  const float pdf = emitter_pdf<true>(S, h, o, d);
+  if (live) out[i] = pdf;
+}
+hipError_t launch_emitter_pdf(const LaunchConfig& cfg, const SceneView& S, uint32_t n, const float* o, const float* d, float* out, hipStream_t st) {
+  size_t lds = (size_t)cfg.stack_depth * BLOCK * sizeof(uint32_t);
+  dim3 grid((n + BLOCK - 1) / BLOCK), block(BLOCK);
+  if (cfg.features & FEAT_SMALL) hipLaunchKernelGGL(emitter_pdf_kernel<true>, grid, block, 0, st, S, n, o, d, out);
+  else hipLaunchKernelGGL(emitter_pdf_kernel<false>, grid, block, lds, st, S, n, o, d, out);
+  return hipGetLastError();
+}
+
+// PCG32si on the device (rene_pcg_probe): one lane, n outputs
+__global__ void pcg_probe_kernel(uint32_t seed, uint32_t n, uint32_t* out) {
+  Pcg r = pcg_new(seed);
+  for (uint32_t k = 0; k < n; ++k) out[k] = pcg_u32(r);
+}
+hipError_t launch_pcg_probe(uint32_t seed, uint32_t n, uint32_t* out, hipStream_t st) {
+  hipLaunchKernelGGL(pcg_probe_kernel, dim3(1), dim3(1), 0, st, seed, n, out);
+  return hipGetLastError();
+}
+
+// owned tiles <-> packed buffer (rene_gather_tiles): one thread per (owned tile, layer, texel), 16 bytes each
+__global__ void __launch_bounds__(BLOCK) pack_tiles_kernel(float* fb, float* packed, uint32_t W, uint32_t H, uint32_t tiles_x, uint32_t n_owned,
+                                                            uint32_t shard_rank, uint32_t shard_count, bool unpack) {
+  const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;  // ((k * 3 + layer) * 32 + ty) * 32 + tx
+  if (i >= (size_t)n_owned * 3u * RENE_TILE_SIZE * RENE_TILE_SIZE) return;
+  const uint32_t tx = (uint32_t)(i & 31u), ty = (uint32_t)((i >> 5) & 31u);
+  const uint32_t kl = (uint32_t)(i >> 10), layer = kl % 3u, k = kl / 3u;
+  const uint32_t tile = shard_rank + k * shard_count;
+  const uint32_t x = (tile % tiles_x) * RENE_TILE_SIZE + tx, y = (tile / tiles_x) * RENE_TILE_SIZE + ty;
+  float4* p = reinterpret_cast<float4*>(packed) + i;
+  if (x < W && y < H) {
+    float4* f = reinterpret_cast<float4*>(fb) + ((size_t)layer * H + y) * W + x;
+    if (unpack) *f = *p;
+    else *p = *f;
+  } else if (!unpack) {
+    *p = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+hipError_t launch_pack_tiles(const float* fb, float* packed, uint32_t width, uint32_t height, uint32_t tiles_x, uint32_t n_tiles,
+                             uint32_t shard_rank, uint32_t shard_count, bool unpack, hipStream_t st) {
+  const uint32_t n_owned = n_tiles > shard_rank ? (n_tiles - shard_rank + shard_count - 1) / shard_count : 0;
+  if (n_owned == 0) return hipSuccess;
+  const size_t n = (size_t)n_owned * 3u * RENE_TILE_SIZE * RENE_TILE_SIZE;
+  hipLaunchKernelGGL(pack_tiles_kernel, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, const_cast<float*>(fb), packed, width, height, tiles_x,
+                     n_owned, shard_rank, shard_count, unpack);
+  return hipGetLastError();
+}
+
+// -------------------------------------------------------------------------------------------------
 // per-function BSDF probe (rene_bsdf_eval): builds the material's lobes at (normal, uv) exactly like
 // the integrator does and returns f(wo,wi), pdf(wo,wi) and one sample_f(wo) drawn from
 // PCG32si::new(seed).  out[12] = f.xyz, pdf, s.wi.xyz, s.f.xyz, s.pdf, len

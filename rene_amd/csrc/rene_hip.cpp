@@ -3,6 +3,8 @@
 #include "../../include/rene_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types only: the library is loaded on demand (rccl() below)
 
 #include <algorithm>
 #include <chrono>
@@ -74,6 +76,67 @@ void set_last_error(const std::string& msg) { g_error = msg; }
 thread_local uint32_t g_launched_blocks = 0;
 }
 
+// ---- RCCL, loaded on demand: a host that never shards keeps running where librccl.so is absent -----------------
+namespace {
+struct Rccl {
+  void* handle = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommInitAll) CommInitAll = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclReduce) Reduce = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  std::string error;
+};
+Rccl* rccl() {
+  static Rccl* r = [] {
+    Rccl* x = new Rccl();
+    // a process that already holds an RCCL (PyTorch ships its own copy) uses that one; else the ROCm installation's
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+      x->handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+      if (x->handle) break;
+    }
+    for (const char* n : names) {
+      if (x->handle) break;
+      x->handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    }
+    if (!x->handle) {
+      x->error = std::string("RCCL is not available: ") + (dlerror() ? dlerror() : "librccl.so not found");
+      return x;
+    }
+    bool ok = true;
+    auto sym = [&](const char* name) {
+      void* p = dlsym(x->handle, name);
+      if (!p) { ok = false; x->error = std::string("RCCL lacks ") + name; }
+      return p;
+    };
+    x->GetUniqueId = reinterpret_cast<decltype(x->GetUniqueId)>(sym("ncclGetUniqueId"));
+    x->CommInitRank = reinterpret_cast<decltype(x->CommInitRank)>(sym("ncclCommInitRank"));
+    x->CommInitAll = reinterpret_cast<decltype(x->CommInitAll)>(sym("ncclCommInitAll"));
+    x->CommDestroy = reinterpret_cast<decltype(x->CommDestroy)>(sym("ncclCommDestroy"));
+    x->Reduce = reinterpret_cast<decltype(x->Reduce)>(sym("ncclReduce"));
+    x->Send = reinterpret_cast<decltype(x->Send)>(sym("ncclSend"));
+    x->Recv = reinterpret_cast<decltype(x->Recv)>(sym("ncclRecv"));
+    x->GroupStart = reinterpret_cast<decltype(x->GroupStart)>(sym("ncclGroupStart"));
+    x->GroupEnd = reinterpret_cast<decltype(x->GroupEnd)>(sym("ncclGroupEnd"));
+    x->GetErrorString = reinterpret_cast<decltype(x->GetErrorString)>(sym("ncclGetErrorString"));
+    if (!ok) { dlclose(x->handle); x->handle = nullptr; }
+    return x;
+  }();
+  return r;
+}
+#define RCCL_TRY(expr)                                                                                   \
+  do {                                                                                                   \
+    ncclResult_t r_ = (expr);                                                                            \
+    if (r_ != ncclSuccess) return fail(RENE_ERR_DEVICE, std::string(#expr) + ": " + R->GetErrorString(r_)); \
+  } while (0)
+}  // namespace
+
 struct rene_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -128,6 +191,13 @@ struct rene_ctx {
   uint64_t frames = 0, launches = 0, owned_pixels = 0, paths = 0;
   double kernel_ms = 0.0, last_ms = 0.0;
   bool handoff_failed = false;
+  // multi-GPU exchange (rene_comm_*): the RCCL communicator this context belongs to
+  ncclComm_t comm = nullptr;
+  int comm_ranks = 0, comm_rank = -1;
+  bool exchanged = false;  // an exchange has rewritten the records' version words: rene_reset before rendering again
+  float* tile_buf = nullptr;  // rene_gather_tiles: packed owned tiles (root: of every rank)
+  int unpack_root = -1;       // >= 0: tiles received by rene_gather_tiles wait in tile_buf to be placed (flush_exchange)
+  size_t tile_buf_floats = 0;
   // seed schedule cache: seeds[k] = k-th next_u32 of PCG32si::new(master)
 
   template <class T>
@@ -171,7 +241,28 @@ struct rene_ctx {
     }
   }
 
+  // root of a rene_gather_tiles: place the other ranks' tiles (enqueued behind the receives on `stream`)
+  int flush_exchange() {
+    if (unpack_root < 0) return RENE_OK;
+    const uint32_t n = (uint32_t)comm_ranks;
+    const size_t tile_floats = (size_t)3 * RENE_TILE_SIZE * RENE_TILE_SIZE * 4;
+    size_t off = 0;
+    for (uint32_t r = 0; r < n; ++r) {
+      const uint32_t owned_r = n_tiles > r ? (n_tiles - r + n - 1) / n : 0u;
+      if ((int)r == unpack_root || owned_r == 0) continue;
+      hipError_t e = rene::launch_pack_tiles(fb, tile_buf + off, width, height, tiles_x, n_tiles, r, n, true, stream);
+      if (e != hipSuccess) return fail(RENE_ERR_DEVICE, std::string("rene_gather_tiles unpack: ") + hipGetErrorString(e));
+      off += owned_r * tile_floats;
+    }
+    unpack_root = -1;
+    return RENE_OK;
+  }
+
   int drain() {  // wait for the stream(s) and fold finished launches into the timing totals
+    {
+      int rc_ = flush_exchange();
+      if (rc_ != RENE_OK) return rc_;
+    }
     HIP_TRY(hipStreamSynchronize(stream));
     if (stream2) HIP_TRY(hipStreamSynchronize(stream2));
     const bool had_launches = !pending.empty();
@@ -473,6 +564,8 @@ void rene_destroy(rene_ctx* c) {
   if (c->d_item_done) hipFree(c->d_item_done);
   if (c->h_done) hipHostFree(c->h_done);
   if (c->h_resident) hipHostFree(c->h_resident);
+  if (c->tile_buf) hipFree(c->tile_buf);
+  if (c->comm && rccl()->handle) rccl()->CommDestroy(c->comm);
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
   delete c;
 }
@@ -480,6 +573,7 @@ void rene_destroy(rene_ctx* c) {
 static int rene_render_impl(rene_ctx* c, uint32_t first_frame, uint32_t n_frames) {
   if (!c) return fail(RENE_ERR_INVALID_ARGUMENT, "rene_render: NULL context");
   if (n_frames == 0) return RENE_OK;
+  if (c->exchanged) return fail(RENE_ERR_INVALID_ARGUMENT, "the image has been through rene_reduce / rene_gather_tiles: rene_reset before rendering again");
   if ((uint64_t)first_frame + n_frames > 0xffffffffull) return fail(RENE_ERR_INVALID_ARGUMENT, "frame range overflows u32");
   HIP_TRY(hipSetDevice(c->device));
   // seed schedule: frame k -> k-th next_u32 of PCG32si::new(master)
@@ -641,6 +735,7 @@ int rene_reset(rene_ctx* c) {
   int rc = c->drain();
   if (rc != RENE_OK && !c->handoff_failed) return rc;
   c->handoff_failed = false;  // the counters are cleared below and the image starts again from zero
+  c->exchanged = false;
   HIP_TRY(hipMemsetAsync(c->fb, 0, c->fb_floats * sizeof(float), c->stream));
   HIP_TRY(hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream));
   HIP_TRY(hipMemsetAsync(c->d_item_done, 0, std::max<size_t>(1, c->n_work) * sizeof(uint32_t), c->stream));
@@ -688,11 +783,9 @@ int rene_framebuffer(rene_ctx* c, void** device_ptr, size_t* n_floats) {
   if (!c || !device_ptr) return fail(RENE_ERR_INVALID_ARGUMENT, "rene_framebuffer: NULL argument");
   *device_ptr = c->fb;
   if (n_floats) *n_floats = c->fb_floats;
-  if (c->overlap()) {  // what the caller enqueues on the context's stream next comes after every launch
-    HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(c->join());
-  }
-  return RENE_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  if (c->overlap()) HIP_TRY(c->join());  // what the caller enqueues on the context's stream next comes after every launch
+  return c->flush_exchange();
 }
 
 static int rene_download_impl(rene_ctx* c, int layer, int channels, float* dst, size_t dst_floats) {
@@ -818,6 +911,172 @@ int rene_medium_eval(rene_ctx* c, uint32_t medium_index, size_t n, const float* 
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   for (int i = 0; i < 6; ++i) hipFree(d[i]);
   if (e != hipSuccess) return fail(RENE_ERR_DEVICE, std::string("rene_medium_eval: ") + hipGetErrorString(e));
+  return RENE_OK;
+}
+
+int rene_emitter_pdf(rene_ctx* c, size_t n, const float* origins, const float* directions, float* out) {
+  if (!c || (n && (!origins || !directions || !out))) return fail(RENE_ERR_INVALID_ARGUMENT, "rene_emitter_pdf: NULL argument");
+  if (n == 0) return RENE_OK;
+  if (n > 0x7fffffffull) return fail(RENE_ERR_INVALID_ARGUMENT, "too many rays in one batch");
+  HIP_TRY(hipSetDevice(c->device));
+  float *d_o = nullptr, *d_d = nullptr, *d_p = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_o), n * 12);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_d), n * 12);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_p), n * 4);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_o, origins, n * 12, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_d, directions, n * 12, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = rene::launch_emitter_pdf(c->cfg, c->view, (uint32_t)n, d_o, d_d, d_p, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(out, d_p, n * 4, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  hipFree(d_o);
+  hipFree(d_d);
+  hipFree(d_p);
+  if (e != hipSuccess) return fail(RENE_ERR_DEVICE, std::string("rene_emitter_pdf: ") + hipGetErrorString(e));
+  return RENE_OK;
+}
+
+int rene_pcg_probe(int device, uint32_t seed, uint32_t n, uint32_t* out) {
+  if (n && !out) return fail(RENE_ERR_INVALID_ARGUMENT, "rene_pcg_probe: NULL argument");
+  if (n == 0) return RENE_OK;
+  int n_dev = 0;
+  HIP_TRY(hipGetDeviceCount(&n_dev));
+  if (device < 0 || device >= n_dev) return fail(n_dev <= 0 ? RENE_ERR_DEVICE : RENE_ERR_INVALID_ARGUMENT, "rene_pcg_probe: no such HIP device");
+  HIP_TRY(hipSetDevice(device));
+  uint32_t* d = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), (size_t)n * 4));
+  hipError_t e = rene::launch_pcg_probe(seed, n, d, nullptr);
+  if (e == hipSuccess) e = hipMemcpy(out, d, (size_t)n * 4, hipMemcpyDeviceToHost);
+  hipFree(d);
+  if (e != hipSuccess) return fail(RENE_ERR_DEVICE, std::string("rene_pcg_probe: ") + hipGetErrorString(e));
+  return RENE_OK;
+}
+
+// ---- multi-GPU exchange step: RCCL over xGMI (include/rene_hip.h) ------------------------------------------------
+static_assert(RENE_COMM_ID_BYTES == sizeof(ncclUniqueId), "rene_comm_unique_id hands out an ncclUniqueId");
+
+int rene_comm_unique_id(uint8_t id[RENE_COMM_ID_BYTES]) {
+  if (!id) return fail(RENE_ERR_INVALID_ARGUMENT, "rene_comm_unique_id: NULL argument");
+  Rccl* R = rccl();
+  if (!R->handle) return fail(RENE_ERR_UNSUPPORTED, R->error);
+  ncclUniqueId u;
+  RCCL_TRY(R->GetUniqueId(&u));
+  std::memcpy(id, &u, sizeof(u));
+  return RENE_OK;
+}
+
+int rene_comm_init(rene_ctx* c, int n_ranks, int rank, const uint8_t id[RENE_COMM_ID_BYTES]) {
+  if (!c || !id) return fail(RENE_ERR_INVALID_ARGUMENT, "rene_comm_init: NULL argument");
+  if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(RENE_ERR_INVALID_ARGUMENT, "rene_comm_init: rank out of range");
+  if (c->comm) return fail(RENE_ERR_INVALID_ARGUMENT, "rene_comm_init: the context already belongs to a communicator");
+  Rccl* R = rccl();
+  if (!R->handle) return fail(RENE_ERR_UNSUPPORTED, R->error);
+  HIP_TRY(hipSetDevice(c->device));
+  ncclUniqueId u;
+  std::memcpy(&u, id, sizeof(u));
+  RCCL_TRY(R->CommInitRank(&c->comm, n_ranks, u, rank));
+  c->comm_ranks = n_ranks;
+  c->comm_rank = rank;
+  return RENE_OK;
+}
+
+int rene_comm_init_all(rene_ctx** ctxs, int n) {
+  if (!ctxs || n < 1) return fail(RENE_ERR_INVALID_ARGUMENT, "rene_comm_init_all: NULL argument");
+  std::vector<int> devs(n);
+  for (int i = 0; i < n; ++i) {
+    if (!ctxs[i] || ctxs[i]->comm) return fail(RENE_ERR_INVALID_ARGUMENT, "rene_comm_init_all: NULL context or context already in a communicator");
+    devs[i] = ctxs[i]->device;
+  }
+  Rccl* R = rccl();
+  if (!R->handle) return fail(RENE_ERR_UNSUPPORTED, R->error);
+  std::vector<ncclComm_t> comms(n);
+  RCCL_TRY(R->CommInitAll(comms.data(), n, devs.data()));
+  for (int i = 0; i < n; ++i) {
+    ctxs[i]->comm = comms[i];
+    ctxs[i]->comm_ranks = n;
+    ctxs[i]->comm_rank = i;
+  }
+  return RENE_OK;
+}
+
+int rene_comm_group_begin(void) {
+  Rccl* R = rccl();
+  if (!R->handle) return fail(RENE_ERR_UNSUPPORTED, R->error);
+  RCCL_TRY(R->GroupStart());
+  return RENE_OK;
+}
+int rene_comm_group_end(void) {
+  Rccl* R = rccl();
+  if (!R->handle) return fail(RENE_ERR_UNSUPPORTED, R->error);
+  RCCL_TRY(R->GroupEnd());
+  return RENE_OK;
+}
+
+int rene_reduce(rene_ctx* c, int root) {
+  if (!c) return fail(RENE_ERR_INVALID_ARGUMENT, "rene_reduce: NULL context");
+  if (!c->comm) return fail(RENE_ERR_INVALID_ARGUMENT, "rene_reduce: rene_comm_init first");
+  if (root < 0 || root >= c->comm_ranks) return fail(RENE_ERR_INVALID_ARGUMENT, "rene_reduce: root out of range");
+  Rccl* R = rccl();
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(c->join());  // the collective runs on `stream`, behind every launch of both streams
+  c->exchanged = true;
+  RCCL_TRY(R->Reduce(c->fb, c->fb, c->fb_floats, ncclFloat, ncclSum, root, c->comm, c->stream));
+  return RENE_OK;
+}
+
+int rene_gather_tiles(rene_ctx* c, int root) {
+  if (!c) return fail(RENE_ERR_INVALID_ARGUMENT, "rene_gather_tiles: NULL context");
+  if (!c->comm) return fail(RENE_ERR_INVALID_ARGUMENT, "rene_gather_tiles: rene_comm_init first");
+  if (root < 0 || root >= c->comm_ranks) return fail(RENE_ERR_INVALID_ARGUMENT, "rene_gather_tiles: root out of range");
+  const uint32_t n = (uint32_t)c->comm_ranks;
+  if (c->opts.shard_mode != RENE_SHARD_TILES || c->opts.shard_count != n || c->opts.shard_rank != (uint32_t)c->comm_rank)
+    return fail(RENE_ERR_INVALID_ARGUMENT, "rene_gather_tiles: the context must be tile-sharded with shard_count == n_ranks and shard_rank == rank");
+  Rccl* R = rccl();
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(c->join());
+  c->exchanged = true;
+  const size_t tile_floats = (size_t)3 * RENE_TILE_SIZE * RENE_TILE_SIZE * 4;
+  auto owned = [&](uint32_t r) { return c->n_tiles > r ? (c->n_tiles - r + n - 1) / n : 0u; };
+  const bool is_root = c->comm_rank == root;
+  // packed staging: a sender its own tiles; the root those of every other rank, one after the other
+  size_t need = 0;
+  if (n == 1) need = owned(0) * tile_floats;
+  else if (is_root) { for (uint32_t r = 0; r < n; ++r) if ((int)r != root) need += owned(r) * tile_floats; }
+  else need = owned((uint32_t)c->comm_rank) * tile_floats;
+  if (need > c->tile_buf_floats) {
+    if (c->tile_buf) hipFree(c->tile_buf);
+    c->tile_buf = nullptr;
+    c->tile_buf_floats = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->tile_buf), std::max<size_t>(16, need * sizeof(float))));
+    c->tile_buf_floats = need;
+  }
+  if (n == 1) {
+    // a communicator of one has nothing to send; it still packs its tiles, clears the image and places them again, so
+    // that the two kernels of the exchange run (and are tested) wherever the library does
+    hipError_t e = rene::launch_pack_tiles(c->fb, c->tile_buf, c->width, c->height, c->tiles_x, c->n_tiles, 0u, 1u, false, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->fb, 0, c->fb_floats * sizeof(float), c->stream);
+    if (e == hipSuccess) e = rene::launch_pack_tiles(c->fb, c->tile_buf, c->width, c->height, c->tiles_x, c->n_tiles, 0u, 1u, true, c->stream);
+    if (e != hipSuccess) return fail(RENE_ERR_DEVICE, std::string("rene_gather_tiles: ") + hipGetErrorString(e));
+    return RENE_OK;
+  }
+  if (!is_root) {
+    hipError_t e = rene::launch_pack_tiles(c->fb, c->tile_buf, c->width, c->height, c->tiles_x, c->n_tiles, (uint32_t)c->comm_rank, n, false, c->stream);
+    if (e != hipSuccess) return fail(RENE_ERR_DEVICE, std::string("rene_gather_tiles pack: ") + hipGetErrorString(e));
+    if (need) RCCL_TRY(R->Send(c->tile_buf, need, ncclFloat, root, c->comm, c->stream));
+    return RENE_OK;
+  }
+  RCCL_TRY(R->GroupStart());
+  size_t off = 0;
+  for (uint32_t r = 0; r < n; ++r) {
+    if ((int)r == root || owned(r) == 0) continue;
+    ncclResult_t rr = R->Recv(c->tile_buf + off, owned(r) * tile_floats, ncclFloat, (int)r, c->comm, c->stream);
+    if (rr != ncclSuccess) { R->GroupEnd(); return fail(RENE_ERR_DEVICE, std::string("ncclRecv: ") + R->GetErrorString(rr)); }
+    off += owned(r) * tile_floats;
+  }
+  RCCL_TRY(R->GroupEnd());
+  // the received tiles are placed by the next call that waits for or hands out the image (rene_sync, rene_download,
+  // rene_get_stats, rene_framebuffer): inside a caller's rene_comm_group_begin / _end the receives above are only
+  // enqueued when the outermost group ends, and the placing kernels must come behind them on the stream
+  c->unpack_root = root;
   return RENE_OK;
 }
 

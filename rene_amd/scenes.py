@@ -177,9 +177,10 @@ def _plate(A, B, Cc, D, n0, n4) -> TriangleMesh:
     return _box(np.asarray(P, dtype=F32).reshape(-1), [n0, neg(n0), (0, 0, -1), (0, 0, 1), n4, neg(n4)])
 
 
-def veach_mis(xres: int = 1280, yres: int = 720) -> Scene:
+def veach_mis(xres: int = 1280, yres: int = 720, small_light: bool = True) -> Scene:
     """52 triangles + 3 emissive spheres (r = 1, 0.5, 0.05), four metal plates with
-    alpha = 0.01 / 0.05 / 0.1 / 0.25 (`remaproughness false`), two Matte walls."""
+    alpha = 0.01 / 0.05 / 0.1 / 0.25 (`remaproughness false`), two Matte walls.  small_light=False leaves the
+    r = 0.05 emitter out (parity tests: rene's fp32 cone pdf cancels catastrophically for it, lib.rs:1058-1064)."""
     s = Scene.new()
     s.film.filename = "veach-mis.png"
     s.set_camera(glam.from_cols_array(VEACH_WORLD_TO_CAMERA), VEACH_FOV_DEG, xres, yres)
@@ -199,6 +200,8 @@ def veach_mis(xres: int = 1280, yres: int = 720) -> Scene:
     s.add_triangle_mesh(_quad([-5, 19.8, 23.76, -5, 0, 23.76, -5, 0, -23.76, -5, 19.8, -23.76],
                               (1, -4.37114e-08, -2.09815e-07)), diffuse)
     for L, z, r in ((7.599088, -2.8, 1.0), (30.396353, 0.0, 0.5), (3039.635254, 2.7, 0.05)):
+        if r < 0.1 and not small_light:
+            continue
         al = s.add_area_light_diffuse((L, L, L))
         s.add_sphere(r, null, area_light=al, ctm=glam.from_translation((0, 6.5, z)))
     s.add_triangle_mesh(_plate((9.61645, 1.21286), (11.7008, 0.956897), (9.65301, 1.51062), (11.7374, 1.25466),
@@ -352,3 +355,52 @@ def teapot_class(xres: int = 1920, yres: int = 1080, n_lat: int = 250, n_lon: in
     s.add_triangle_mesh(displaced_sphere(n_lat, n_lon, radius=0.8, amplitude=0.18, seed=11), body,
                         ctm=glam.from_translation((0.0, 0.95, 0.0)))
     return s
+
+
+# ---------------------------------------------------------------------------------------------------
+# teapot-full-class from the reference's own scene file and meshes (tests/golden/teapot: data fixture)
+# ---------------------------------------------------------------------------------------------------
+def synthetic_sky(width: int = 1024, height: int = 512) -> np.ndarray:
+    """(height, width, 3) float32 environment map: a vertical gradient with a sun -- the stand-in for the scene's
+    textures/envmap.pfm, which rene's checkout lacks (.MISSING_LARGE_BLOBS)."""
+    v = np.linspace(0.0, 1.0, height, dtype=F32)[:, None]
+    u = np.linspace(0.0, 1.0, width, dtype=F32)[None, :]
+    sky = np.empty((height, width, 3), dtype=F32)
+    sky[..., 0] = 0.35 + 0.5 * v
+    sky[..., 1] = 0.45 + 0.4 * v
+    sky[..., 2] = 0.75 + 0.15 * v
+    sun = np.exp(-((u - 0.3) ** 2 + (v - 0.75) ** 2) / 0.002).astype(F32)
+    return (sky + 6.0 * sun[..., None]).astype(F32)
+
+
+def write_pfm(path: str, rgb: np.ndarray):
+    """Colour PFM, little endian, bottom row first (rene/src/scene/pfm_parser.rs:10-61 reads it back)."""
+    h, w, _ = rgb.shape
+    with open(path, "wb") as f:
+        f.write(f"PF\n{w} {h}\n-1.0\n".encode())
+        f.write(np.ascontiguousarray(rgb[::-1], dtype="<f4").tobytes())
+
+
+def teapot_full(xres: int = 1920, yres: int = 1080, asset_dir: str | None = None):
+    """BASELINE config 5 from the reference's own inputs: sample_scenes/teapot/scene.pbrt (Substrate teapot, checkerboard
+    Matte floor, infinite light with an environment map; 126 048 triangles) loaded through the pbrt-v3 loader
+    (rene_scene_load_pbrt), with the Film size replaced and a synthetic 1024x512 sky as textures/envmap.pfm.
+    Returns a rene_amd.loader.LoadedScene."""
+    import os
+    import re
+    import shutil
+    import tempfile
+    from . import loader
+    src = asset_dir or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "teapot")
+    tmp = tempfile.mkdtemp(prefix="rene_teapot_")
+    try:
+        text = open(os.path.join(src, "scene.pbrt")).read()
+        text = re.sub(r'"integer xresolution" \[ \d+ \]', f'"integer xresolution" [ {xres} ]', text)
+        text = re.sub(r'"integer yresolution" \[ \d+ \]', f'"integer yresolution" [ {yres} ]', text)
+        open(os.path.join(tmp, "scene.pbrt"), "w").write(text)
+        os.symlink(os.path.join(src, "models"), os.path.join(tmp, "models"))
+        os.makedirs(os.path.join(tmp, "textures"))
+        write_pfm(os.path.join(tmp, "textures", "envmap.pfm"), synthetic_sky())
+        return loader.load_pbrt(os.path.join(tmp, "scene.pbrt"))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)

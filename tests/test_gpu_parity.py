@@ -94,6 +94,27 @@ def test_cornell_image_and_counters(cornell128):
     assert r.download(0, 4)[..., 3].max() == 0.0  # alpha is never written (lib.rs:170)
 
 
+@pytest.mark.parametrize("flags", [0, abi.FLAG_NO_AOV, abi.FLAG_OVERLAP])
+def test_production_instantiations_against_the_oracle(oracle_mod, flags):
+    """The kernels the bench and the CLI run -- render_kernel<..., COUNT = false, AOV = true> (and the no-AOV variant) --
+    not the counting instantiation the other parity tests use (RENE_FLAG_COUNTERS selects <true, true>): Cornell at
+    256 x 256 x 16 spp against the oracle at the T1 tolerance."""
+    s = scenes.cornell_box(256, 256)
+    o = oracle_mod.Oracle(s)
+    o.render(0, 16)
+    with api.Renderer(s, flags=flags) as r:
+        r.render(0, 10)
+        r.render(10, 6)
+        so, sg = o.stats().as_dict(), r.stats().as_dict()
+        assert sg["paths"] == so["paths"] == 256 * 256 * 16
+        for k in ("rays_closest", "rays_emitter", "hits"):
+            assert abs(sg[k] - so[k]) <= 1e-4 * so[k] + 2, (k, sg[k], so[k])
+        t1_check(r.download(0), o.download(0))
+        if not (flags & abi.FLAG_NO_AOV):
+            aov_check(r.download(1), o.download(1), atol=2e-5 * 16)
+            aov_check(r.download(2), o.download(2), atol=1e-6 * 16)
+
+
 def test_committed_fixture(oracle_mod):
     want = np.load(os.path.join(GOLDEN, "cornell_64x64_4spp_layers.npy"))
     with api.Renderer(scenes.cornell_box(64, 64)) as r:

@@ -224,3 +224,56 @@ def test_every_work_item_cut_and_rene_tune_give_the_same_bits(name, monkeypatch)
             r.render(13, 7)
             for k in range(3):
                 np.testing.assert_array_equal(r.download(k), want[k])
+
+
+# ---- the BASELINE configurations at their own sizes (configs_untested) ---------------------------------
+def test_teapot_full_126k_triangles_against_the_oracle(oracle_mod):
+    """BASELINE config 5 with the reference's own inputs (tests/golden/teapot: rene's scene.pbrt + its two PLY meshes,
+    126 050 triangles, through the pbrt loader) at a size the oracle finishes in seconds."""
+    s = scenes.teapot_full(192, 108)
+    info = api.pack_info(s)
+    assert info.n_triangles == 126050 and not (info.features & 64)
+    sg, so = _compare(s, 8, oracle_mod, frac=5e-3, relmse=1e-3, ctol=2e-3)
+    assert sg["rays_emitter"] == 0 and sg["rays_shadow"] == 0 and sg["hits"] > 0
+    o = oracle_mod.Oracle(s)
+    rng = np.random.default_rng(9)
+    rays = [o.camera_ray(float(u), float(v)) for u, v in rng.uniform(0.02, 0.98, size=(6000, 2))]
+    org, d = np.stack([r[0] for r in rays]).astype(np.float32), np.stack([r[1] for r in rays]).astype(np.float32)
+    with api.Renderer(s) as r:
+        hg, ho = r.trace(org, d), o.trace(org, d)
+    tie = np.abs(hg["t"] - ho["t"]) <= 2e-5 * (1 + np.abs(ho["t"]))
+    bad = ((hg["t"] < 0) != (ho["t"] < 0)) | ((ho["t"] >= 0) & ((hg["primitive"] != ho["primitive"]) | (hg["instance"] != ho["instance"])) & ~tie)
+    assert (ho["t"] > 0).sum() > 3000 and bad.sum() <= 3, bad.sum()
+
+
+@pytest.mark.parametrize("name", ["dragon-class", "teapot-full"])
+def test_full_size_configs_hold_their_invariants(name):
+    """C4 / C5 at 1920x1080 (the oracle would take minutes here): what does not depend on size -- the image is finite and
+    non-empty, a job cut into launches, into overlapping launches and into tile shards is bit-identical, paths = pixels x
+    frames, and the per-ray statistics equal those of the size the oracle checks."""
+    big = scenes.dragon_class(1920, 1080) if name == "dragon-class" else scenes.teapot_full(1920, 1080)
+    small = scenes.dragon_class(240, 136) if name == "dragon-class" else scenes.teapot_full(192, 108)
+    frames = 6
+    with api.Renderer(big) as r:
+        r.render(0, frames)
+        whole = [r.download(l) for l in range(3)]
+        st = r.stats().as_dict()
+    assert st["paths"] == 1920 * 1080 * frames and all(np.isfinite(w).all() for w in whole) and whole[0].mean() > 0
+    with api.Renderer(big, flags=abi.FLAG_OVERLAP) as r:
+        r.render(0, 2); r.render(2, 3); r.render(5, 1)
+        for l in range(3):
+            assert np.array_equal(r.download(l), whole[l])
+    acc = [np.zeros_like(w) for w in whole]
+    for rank in range(2):
+        with api.Renderer(big, shard_mode=abi.SHARD_TILES, shard_rank=rank, shard_count=2) as r:
+            r.render(0, frames)
+            for l in range(3):
+                acc[l] += r.download(l)
+    for l in range(3):
+        assert np.array_equal(acc[l], whole[l])
+    with api.Renderer(small) as r:
+        r.render(0, frames)
+        ss = r.stats().as_dict()
+    for k in ("rays_closest", "rays_shadow", "hits", "adds"):  # per path, within a few per cent of the small render
+        a, b = st[k] / st["paths"], ss[k] / ss["paths"]
+        assert abs(a - b) <= 0.06 * max(b, 1e-9) + 1e-3, (k, a, b)
