@@ -89,6 +89,24 @@ RENE_DEV uint32_t pcg_u32(Pcg& r) {  // rand.rs:19-22, 32-36
   uint32_t word = ((s >> ((s >> 28) + 4u)) ^ s) * 277803737u;
   return (word >> 22) ^ word;
 }
+// The build-defined seed schedule (SURVEY section 8 d): the seed of global frame g is the g-th next_u32() of
+// PCG32si::new(master).  Computed where it is needed by jumping the generator ahead (the LCG's g-fold composition by
+// repeated squaring, at most 32 rounds) -- no seed table travels to the device: a launch is a kernel launch and two event
+// records, nothing that needs a copy engine or a free CU slot while persistent kernels hold the chip.
+RENE_DEV uint32_t frame_seed(uint32_t state0, uint32_t g) {
+  uint32_t mul = 747796405u, add = 2891336453u, acc_mul = 1u, acc_add = 0u;
+  for (; g; g >>= 1) {
+    if (g & 1u) {
+      acc_mul *= mul;
+      acc_add = acc_add * mul + add;
+    }
+    add = (mul + 1u) * add;
+    mul *= mul;
+  }
+  const uint32_t s = acc_mul * state0 + acc_add;
+  const uint32_t word = ((s >> ((s >> 28) + 4u)) ^ s) * 277803737u;
+  return (word >> 22) ^ word;
+}
 RENE_DEV float pcg_f32(Pcg& r) {  // rand.rs:38-47
   return (1.0f / 16777216.0f) * (float)(pcg_u32(r) >> 8);
 }

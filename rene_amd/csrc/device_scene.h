@@ -238,7 +238,10 @@ enum : uint32_t {
 
 struct RenderParams {
   float* framebuffer;      // [3][H][W][4]: r, g, b sums + the record's version (device_code.inc, fb_store)
-  const uint32_t* seeds;   // n_frames frame seeds
+  uint32_t seed_state0;    // state of PCG32si::new(master seed): the seed of global frame g is the stream's g-th output
+  uint32_t first_frame;    // global number of the launch's frame 0 ...
+  uint32_t frame_stride;   // ... and of the step to its next one (RENE_SHARD_FRAMES deals frames round-robin; else 1)
+  uint32_t pad0_;
   uint32_t* work_counter;  // next work id
   unsigned long long* counters;  // 9 x u64
   uint32_t n_frames;
@@ -260,6 +263,7 @@ struct RenderParams {
   uint32_t* resident;      // RENE_FLAG_OVERLAP: host-visible [waves]; every wave stores `epoch` here when it starts, so the
                            // host can tell that the whole launch is resident before it submits the next one (else null)
   float inv_n_work, inv_tiles_x;  // 1.0f / n_work, 1.0f / tiles_x (udiv_small in the work-item bookkeeping)
+  unsigned long long* wave_times;  // RENE_DEBUG: [waves][2] start / end of every wave on the 100 MHz clock, else null
 };
 
 }  // namespace rene

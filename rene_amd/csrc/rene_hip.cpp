@@ -146,7 +146,6 @@ struct rene_ctx {
   // order the two launches' updates of a pixel through the version its records carry, device_code.inc item_load)
   hipStream_t stream2 = nullptr;
   hipEvent_t join_event = nullptr;
-  uint32_t* d_work_counter2 = nullptr;
   uint32_t* h_resident = nullptr;   // pinned, one word per wave of a launch (RenderParams::resident)
   uint32_t resident_words = 0;
   rene_opts opts{};
@@ -157,7 +156,10 @@ struct rene_ctx {
   float* fb = nullptr;
   bool own_fb = false;
   size_t fb_floats = 0;
-  uint32_t* d_work_counter = nullptr;
+  static constexpr uint32_t kCounters = 60;  // launches between two drains: each takes its own zeroed work counter
+  uint32_t* d_work_counters = nullptr;        // [kCounters]
+  unsigned long long* d_wave_times = nullptr; // RENE_DEBUG: [kCounters][8192][2]
+  uint32_t counters_used = 0;
   uint32_t epoch = 0, prev_final = 0;
   // frames per work item: kWholeLaunch = one item per pixel and launch; 0 = not tuned (rene_tune picks): four items per
   // pixel for the item-loop kernels, whose item switches cost one memory round trip, eight for the BVH kernels, where
@@ -174,7 +176,6 @@ struct rene_ctx {
   // per-launch resources that must outlive the asynchronous launch
   struct Pending {
     hipEvent_t start, stop;
-    uint32_t* d_seeds;
     bool second_stream;
     uint32_t epoch, waves;
   };
@@ -191,11 +192,14 @@ struct rene_ctx {
   uint64_t frames = 0, launches = 0, owned_pixels = 0, paths = 0;
   double kernel_ms = 0.0, last_ms = 0.0;
   bool handoff_failed = false;
+  std::string handoff_detail;
   // multi-GPU exchange (rene_comm_*): the RCCL communicator this context belongs to
   ncclComm_t comm = nullptr;
   int comm_ranks = 0, comm_rank = -1;
   bool exchanged = false;  // an exchange has rewritten the records' version words: rene_reset before rendering again
   float* tile_buf = nullptr;  // rene_gather_tiles: packed owned tiles (root: of every rank)
+  float* h_stage = nullptr;   // pinned host staging of one layer (rene_download)
+  void* h_upload = nullptr;   // pinned host staging of the scene upload (rene_create), released when it is done
   int unpack_root = -1;       // >= 0: tiles received by rene_gather_tiles wait in tile_buf to be placed (flush_exchange)
   size_t tile_buf_floats = 0;
   // seed schedule cache: seeds[k] = k-th next_u32 of PCG32si::new(master)
@@ -206,8 +210,21 @@ struct rene_ctx {
     void* p = nullptr;
     HIP_TRY(hipMalloc(&p, bytes));
     allocations.push_back(p);
-    if (!v.empty()) HIP_TRY(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
-    else HIP_TRY(hipMemset(p, 0, bytes));
+    if (!v.empty()) {
+      // through pinned staging, in pieces: a copy straight from pageable memory makes the runtime register the caller's
+      // pages with the driver for the duration of the copy (see rene_download)
+      constexpr size_t kPiece = 8u << 20;
+      if (!h_upload) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h_upload), kPiece, hipHostMallocDefault));
+      const char* src = reinterpret_cast<const char*>(v.data());
+      const size_t total = v.size() * sizeof(T);
+      for (size_t off = 0; off < total; off += kPiece) {
+        const size_t n = std::min(kPiece, total - off);
+        std::memcpy(h_upload, src + off, n);
+        HIP_TRY(hipMemcpy(static_cast<char*>(p) + off, h_upload, n, hipMemcpyHostToDevice));
+      }
+    } else {
+      HIP_TRY(hipMemset(p, 0, bytes));
+    }
     *out = static_cast<const T*>(p);
     return RENE_OK;
   }
@@ -225,14 +242,30 @@ struct rene_ctx {
     if (pending.empty() || pending.back().second_stream == second_stream) return RENE_OK;
     const Pending& prev = pending.back();
     const auto t0 = std::chrono::steady_clock::now();
+    if (std::getenv("RENE_DEBUG")) {
+      uint32_t n_eq = 0, n_other = 0, first_other = 0;
+      for (uint32_t w = 0; w < prev.waves; ++w) {
+        const uint32_t v = __atomic_load_n(&h_resident[w], __ATOMIC_ACQUIRE);
+        if (v == prev.epoch) n_eq++;
+        else if (!n_other++) first_other = v;
+      }
+      std::fprintf(stderr, "[rene] admit: launch %u has %u waves; at entry %u announce it, %u hold another value (e.g. %u); h_resident %p\n", prev.epoch, prev.waves, n_eq, n_other, first_other, (void*)h_resident);
+    }
     for (uint64_t spins = 0;; ++spins) {
       bool all = true;
       for (uint32_t w = 0; w < prev.waves && all; ++w)
         all = __atomic_load_n(&h_resident[w], __ATOMIC_ACQUIRE) == prev.epoch;
-      if (all) return RENE_OK;
+      if (all) {
+        if (std::getenv("RENE_DEBUG")) std::fprintf(stderr, "[rene] admit: launch %u resident after %.3f ms\n", prev.epoch, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        return RENE_OK;
+      }
       if ((spins & 63u) == 63u) {
-        if (hipEventQuery(prev.stop) == hipSuccess) return RENE_OK;  // it has come and gone
+        if (hipEventQuery(prev.stop) == hipSuccess) {
+          if (std::getenv("RENE_DEBUG")) std::fprintf(stderr, "[rene] admit: launch %u already over\n", prev.epoch);
+          return RENE_OK;  // it has come and gone
+        }
         if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
+          if (std::getenv("RENE_DEBUG")) std::fprintf(stderr, "[rene] admit: launch %u not resident after 200 ms, waiting for it\n", prev.epoch);
           // a device shared with other work may keep part of that launch out for long: then simply let it finish
           HIP_TRY(hipEventSynchronize(prev.stop));
           return RENE_OK;
@@ -266,25 +299,53 @@ struct rene_ctx {
     HIP_TRY(hipStreamSynchronize(stream));
     if (stream2) HIP_TRY(hipStreamSynchronize(stream2));
     const bool had_launches = !pending.empty();
+    if (counters_used && d_wave_times) {  // RENE_DEBUG: per launch, when its waves started and ended (ms since the first start)
+      std::vector<unsigned long long> t((size_t)counters_used * 8192 * 2);
+      if (hipMemcpy(t.data(), d_wave_times, t.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+        unsigned long long t0 = ~0ull;
+        for (auto v : t) if (v && v < t0) t0 = v;
+        for (uint32_t k = 0; k < counters_used; ++k) {
+          std::vector<double> st, en;
+          for (uint32_t w = 0; w < 8192; ++w) {
+            const unsigned long long a = t[((size_t)k * 8192 + w) * 2], b = t[((size_t)k * 8192 + w) * 2 + 1];
+            if (a) st.push_back((a - t0) * 1e-5);
+            if (b) en.push_back((b - t0) * 1e-5);
+          }
+          std::sort(st.begin(), st.end());
+          std::sort(en.begin(), en.end());
+          auto q = [](const std::vector<double>& v, double f) { return v.empty() ? -1.0 : v[(size_t)(f * (v.size() - 1))]; };
+          std::fprintf(stderr, "[rene] launch slot %u: %zu waves; starts min/50%%/90%%/max %.3f %.3f %.3f %.3f ms; ends min/10%%/50%%/90%%/max %.3f %.3f %.3f %.3f %.3f ms\n", k, st.size(),
+                       q(st, 0), q(st, .5), q(st, .9), q(st, 1), q(en, 0), q(en, .1), q(en, .5), q(en, .9), q(en, 1));
+        }
+      }
+      hipMemset(d_wave_times, 0, (size_t)counters_used * 8192 * 2 * 8);
+    }
+    if (counters_used) {  // both streams are idle: the work counters can be handed out again
+      HIP_TRY(hipMemset(d_work_counters, 0, kCounters * sizeof(uint32_t)));
+      counters_used = 0;
+    }
     while (!pending.empty()) {
       Pending& p = pending.front();
       float ms = 0.0f;
       HIP_TRY(hipEventElapsedTime(&ms, p.start, p.stop));
+      if (std::getenv("RENE_DEBUG")) std::fprintf(stderr, "[rene] launch %u: %.3f ms\n", p.epoch, ms);
       kernel_ms += ms;
       last_ms = ms;
       hipEventDestroy(p.start);
       hipEventDestroy(p.stop);
-      hipFree(p.d_seeds);
       pending.pop_front();
     }
     // a work-item hand-off that gave up (device_code.inc, `give_up`) took the sums as they were: the image is wrong, and
     // every call that hands results to the caller (rene_sync, rene_download, rene_get_stats, rene_reduce) must say so
     if (had_launches && d_counters && !handoff_failed) {
-      unsigned long long timeouts = 0;
-      HIP_TRY(hipMemcpy(&timeouts, d_counters + 8, sizeof(timeouts), hipMemcpyDeviceToHost));
-      handoff_failed = timeouts != 0;
+      unsigned long long t[4] = {0, 0, 0, 0};
+      HIP_TRY(hipMemcpy(t, d_counters + 8, sizeof(t), hipMemcpyDeviceToHost));
+      handoff_failed = t[0] != 0;
+      if (handoff_failed)
+        handoff_detail = " [" + std::to_string(t[0]) + " lanes gave up; the first: work id " + std::to_string(t[1]) + " of " + std::to_string(n_work) + " slots per level, in launch " +
+                         std::to_string(t[2] >> 32) + ", wanted version " + std::to_string(t[3]) + ", saw " + std::to_string(t[2] & 0xffffffffu) + "]";
     }
-    if (handoff_failed) return fail(RENE_ERR_DEVICE, "a work-item hand-off timed out inside the render kernel (results invalid; rene_reset clears the condition)");
+    if (handoff_failed) return fail(RENE_ERR_DEVICE, "a work-item hand-off timed out inside the render kernel (results invalid; rene_reset clears the condition)" + handoff_detail);
     return RENE_OK;
   }
 };
@@ -523,14 +584,14 @@ static int rene_create_impl(const rene_scene_desc* scene, const rene_opts* opts,
     HIP_TRY(dev(reinterpret_cast<void**>(&q.wave_sums), ((n + 255) / 256) * 4 * 8 * sizeof(unsigned long long)));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_done), sizeof(uint32_t)));
   }
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_work_counter), sizeof(uint32_t)));
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_work_counters), rene_ctx::kCounters * sizeof(uint32_t)));
+  HIP_TRY(hipMemsetAsync(c->d_work_counters, 0, rene_ctx::kCounters * sizeof(uint32_t), c->stream));
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_counters), 16 * sizeof(unsigned long long)));
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_item_done), std::max<size_t>(1, c->n_work) * sizeof(uint32_t)));
   HIP_TRY(hipMemsetAsync(c->d_item_done, 0, std::max<size_t>(1, c->n_work) * sizeof(uint32_t), c->stream));
   if ((o.flags & RENE_FLAG_OVERLAP) && !c->wavefront) {
     HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&c->join_event, hipEventDisableTiming));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_work_counter2), sizeof(uint32_t)));
     c->resident_words = c->cfg.grid * (uint32_t)(rene::render_block_size() / 64);
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_resident), c->resident_words * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(c->h_resident, 0, c->resident_words * sizeof(uint32_t));
@@ -539,6 +600,10 @@ static int rene_create_impl(const rene_scene_desc* scene, const rene_opts* opts,
   HIP_TRY(hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
 
+  if (c->h_upload) {
+    hipHostFree(c->h_upload);
+    c->h_upload = nullptr;
+  }
   cleanup.armed = false;
   *out = c.release();
   return RENE_OK;
@@ -552,18 +617,19 @@ void rene_destroy(rene_ctx* c) {
   for (auto& p : c->pending) {
     hipEventDestroy(p.start);
     hipEventDestroy(p.stop);
-    hipFree(p.d_seeds);
   }
   for (void* p : c->allocations) hipFree(p);
   if (c->own_fb && c->fb) hipFree(c->fb);
-  if (c->d_work_counter) hipFree(c->d_work_counter);
-  if (c->d_work_counter2) hipFree(c->d_work_counter2);
+  if (c->d_work_counters) hipFree(c->d_work_counters);
+  if (c->d_wave_times) hipFree(c->d_wave_times);
   if (c->join_event) hipEventDestroy(c->join_event);
   if (c->stream2) hipStreamDestroy(c->stream2);
   if (c->d_counters) hipFree(c->d_counters);
   if (c->d_item_done) hipFree(c->d_item_done);
   if (c->h_done) hipHostFree(c->h_done);
   if (c->h_resident) hipHostFree(c->h_resident);
+  if (c->h_stage) hipHostFree(c->h_stage);
+  if (c->h_upload) hipHostFree(c->h_upload);
   if (c->tile_buf) hipFree(c->tile_buf);
   if (c->comm && rccl()->handle) rccl()->CommDestroy(c->comm);
   if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
@@ -576,54 +642,58 @@ static int rene_render_impl(rene_ctx* c, uint32_t first_frame, uint32_t n_frames
   if (c->exchanged) return fail(RENE_ERR_INVALID_ARGUMENT, "the image has been through rene_reduce / rene_gather_tiles: rene_reset before rendering again");
   if ((uint64_t)first_frame + n_frames > 0xffffffffull) return fail(RENE_ERR_INVALID_ARGUMENT, "frame range overflows u32");
   HIP_TRY(hipSetDevice(c->device));
-  // seed schedule: frame k -> k-th next_u32 of PCG32si::new(master)
-  HostPcg gen(c->opts.seed);
-  gen.skip(first_frame);
-  std::vector<uint32_t> seeds;
-  seeds.reserve(n_frames);
-  for (uint32_t k = 0; k < n_frames; ++k) {
-    uint32_t f = first_frame + k;
-    const uint32_t seed_k = gen.next();
-    if (c->opts.shard_mode == RENE_SHARD_FRAMES && c->opts.shard_count > 1 &&
-        f % c->opts.shard_count != c->opts.shard_rank)
-      continue;
-    seeds.push_back(seed_k);
+  // which frames of [first_frame, first_frame + n_frames) are this context's: all of them, or under RENE_SHARD_FRAMES those
+  // with f % shard_count == shard_rank.  The kernels compute the frames' seeds themselves (device_math.h, frame_seed).
+  uint32_t my_first = first_frame, my_stride = 1, my_count = n_frames;
+  if (c->opts.shard_mode == RENE_SHARD_FRAMES && c->opts.shard_count > 1) {
+    const uint32_t n = c->opts.shard_count, r = c->opts.shard_rank;
+    const uint32_t skip = (r + n - first_frame % n) % n;  // frames before the first one with f % n == r
+    my_first = first_frame + skip;
+    my_stride = n;
+    my_count = skip < n_frames ? (n_frames - skip + n - 1) / n : 0;
   }
   c->frames += n_frames;
-  if (seeds.empty() || c->n_work == 0) return RENE_OK;
-  c->paths += (uint64_t)seeds.size() * c->owned_pixels;
+  if (my_count == 0 || c->n_work == 0) return RENE_OK;
+  c->paths += (uint64_t)my_count * c->owned_pixels;
 
   if (c->epoch >= (1u << 27) - 1u) {  // the hand-off flags are cleared when the epoch wraps: nothing may be in flight then
     int rc = c->drain();
     if (rc != RENE_OK) return rc;
   }
-  // odd launches of an overlapping context go to the second stream, with the second work counter
+  // A launch is a kernel launch between two event records -- no allocation, no copy, no memset: those need a copy engine
+  // or a free CU slot, which a persistent launch that holds the chip gives up only when it ends.  Hence the pool of work
+  // counters (zeroed again in drain()) instead of one that is reset per launch.
+  if (c->counters_used >= rene_ctx::kCounters) {
+    int rc = c->drain();
+    if (rc != RENE_OK) return rc;
+  }
+  // odd launches of an overlapping context go to the second stream
   const bool second_stream = c->overlap() && (c->epoch & 1u);
   if (c->overlap()) {
     int rc = c->admit(second_stream);
     if (rc != RENE_OK) return rc;
   }
   hipStream_t stream = second_stream ? c->stream2 : c->stream;
-  uint32_t* work_counter = second_stream ? c->d_work_counter2 : c->d_work_counter;
-  rene_ctx::Pending pend{};
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&pend.d_seeds), seeds.size() * sizeof(uint32_t)));
-  // pageable source: the copy is staged before hipMemcpyAsync returns, so `seeds` may die
-  hipError_t e = hipMemcpyAsync(pend.d_seeds, seeds.data(), seeds.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream);
-  if (e == hipSuccess) e = hipMemsetAsync(work_counter, 0, sizeof(uint32_t), stream);
-  if (e == hipSuccess) e = hipEventCreate(&pend.start);
-  if (e == hipSuccess) e = hipEventCreate(&pend.stop);
-  if (e != hipSuccess) {
-    hipFree(pend.d_seeds);
-    return fail(RENE_ERR_DEVICE, std::string("rene_render setup: ") + hipGetErrorString(e));
+  uint32_t* work_counter = c->d_work_counters + c->counters_used;
+  if (std::getenv("RENE_DEBUG") && !c->d_wave_times) {
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_wave_times), (size_t)rene_ctx::kCounters * 8192 * 2 * 8));
+    HIP_TRY(hipMemset(c->d_wave_times, 0, (size_t)rene_ctx::kCounters * 8192 * 2 * 8));
   }
+  rene_ctx::Pending pend{};
+  hipError_t e = hipEventCreate(&pend.start);
+  if (e == hipSuccess) e = hipEventCreate(&pend.stop);
+  if (e != hipSuccess) return fail(RENE_ERR_DEVICE, std::string("rene_render setup: ") + hipGetErrorString(e));
   rene::RenderParams P{};
   P.framebuffer = c->fb;
-  P.seeds = pend.d_seeds;
+  P.seed_state0 = HostPcg(c->opts.seed).s;
+  P.first_frame = my_first;
+  P.frame_stride = my_stride;
   P.work_counter = work_counter;
+  P.wave_times = c->d_wave_times ? c->d_wave_times + (size_t)c->counters_used * 8192 * 2 : nullptr;
   P.item_done = c->d_item_done;
-  P.resident = c->h_resident;  // host-coherent memory: the same pointer is valid on the device
+  P.resident = std::getenv("RENE_NO_ANNOUNCE") ? nullptr : c->h_resident;  // host-coherent memory: the same pointer is valid on the device
   P.counters = c->d_counters;
-  P.n_frames = (uint32_t)seeds.size();
+  P.n_frames = my_count;
   P.n_work = c->n_work;
   P.shard_rank = c->opts.shard_mode == RENE_SHARD_TILES ? c->opts.shard_rank : 0;
   P.shard_count = c->opts.shard_mode == RENE_SHARD_TILES ? c->opts.shard_count : 1;
@@ -710,6 +780,7 @@ static int rene_render_impl(rene_ctx* c, uint32_t first_frame, uint32_t n_frames
   hipEventRecord(pend.stop, stream);
   pend.second_stream = second_stream;
   pend.epoch = P.epoch;
+  c->counters_used++;
   pend.waves = std::min(rene::g_launched_blocks * (uint32_t)(rene::render_block_size() / 64), c->resident_words);
   c->pending.push_back(pend);
   if (e != hipSuccess) {
@@ -719,7 +790,7 @@ static int rene_render_impl(rene_ctx* c, uint32_t first_frame, uint32_t n_frames
     return fail(RENE_ERR_DEVICE, std::string("render launch: ") + hipGetErrorString(e));
   }
   c->launches++;
-  if (c->pending.size() > 64) return c->drain();
+  if (c->pending.size() >= rene_ctx::kCounters) return c->drain();
   return RENE_OK;
 }
 
@@ -798,13 +869,20 @@ static int rene_download_impl(rene_ctx* c, int layer, int channels, float* dst, 
   int rc = c->drain();
   if (rc != RENE_OK) return rc;
   const float* src = c->fb + (size_t)layer * n * 4;
+  // through a pinned staging buffer the context keeps: a copy into pageable memory makes the runtime pin and unpin the
+  // destination's pages on the fly (a registration of user memory with the driver per call)
+  if (!c->h_stage) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_stage), n * 4 * sizeof(float), hipHostMallocDefault));
+  HIP_TRY(hipMemcpy(c->h_stage, src, n * 4 * sizeof(float), hipMemcpyDeviceToHost));
+  const float* tmp = c->h_stage;
   if (channels == 4) {
-    HIP_TRY(hipMemcpy(dst, src, n * 4 * sizeof(float), hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < n; ++i) dst[4 * i + 3] = 0.0f;  // the device keeps a record's version there; rene's alpha stays 0 (lib.rs:170)
+    for (size_t i = 0; i < n; ++i) {
+      dst[4 * i] = tmp[4 * i];
+      dst[4 * i + 1] = tmp[4 * i + 1];
+      dst[4 * i + 2] = tmp[4 * i + 2];
+      dst[4 * i + 3] = 0.0f;  // the device keeps a record's version there; rene's alpha stays 0 (lib.rs:170)
+    }
     return RENE_OK;
   }
-  std::vector<float> tmp(n * 4);
-  HIP_TRY(hipMemcpy(tmp.data(), src, n * 4 * sizeof(float), hipMemcpyDeviceToHost));
   for (size_t i = 0; i < n; ++i) {  // f32_4_to_3, rene/src/main.rs:1749-1756
     dst[3 * i] = tmp[4 * i];
     dst[3 * i + 1] = tmp[4 * i + 1];
