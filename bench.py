@@ -64,8 +64,8 @@ def configurations():
         "cornell": ("cornell-box 1024x1024 @ 1024 spp", lambda: scenes.cornell_box(1024, 1024), 1024, 256),
         "veach-mis": ("veach-mis 1024x1024 @ 4096 spp", lambda: scenes.veach_mis(1024, 1024), 4096, 256),
         "dragon-class": ("dragon-class (870 400 triangles, one distant light) 1920x1080 @ 1024 spp", lambda: scenes.dragon_class(1920, 1080), 1024, 64),
-        "teapot-class": ("teapot-full-class (126 048 triangles, Substrate + checkerboard + env map) 1920x1080 @ 8192 spp",
-                         lambda: scenes.teapot_class(1920, 1080), 8192, 128),
+        "teapot-class": ("teapot-full-class: rene's sample_scenes/teapot (126 050 triangles, Substrate + checkerboard + env map) through the "
+                         "pbrt loader, synthetic 1024x512 sky, 1920x1080 @ 8192 spp", lambda: scenes.teapot_full(1920, 1080), 8192, 128),
     }
 
 
@@ -147,8 +147,9 @@ def main():
     label, make, SPP, F = cfgs[head]
     K, Wm = max(1, args.steps), max(0, args.warmup)
     scene = make()
-    packed = scene.to_desc()
+    packed = scene if hasattr(scene, "byref") else scene.to_desc()  # a loaded pbrt scene is its own table owner
     WIDTH, HEIGHT = packed.xres, packed.yres
+    n_triangles = api.pack_info(packed).n_triangles
 
     by_tiles = os.environ.get("RENE_BENCH_SHARD", "frames") == "tiles"
     t_rank, t_world = (rank, world) if by_tiles else (0, 1)
@@ -170,9 +171,21 @@ def main():
             f0, nf = launches[0]
             launches = [(f0, nf // 2), (f0 + nf // 2, nf - nf // 2)]
 
+    # The exchange step runs inside the library (rene_reduce / rene_gather_tiles: ncclReduce / ncclSend+Recv on the
+    # context's stream); torch.distributed only carries the communicator's 128-byte id and the barriers.  With
+    # RENE_DIST_BACKEND=gloo (several ranks on one GPU, which RCCL refuses) the torch-level exchange of rene_amd.dist stands in.
+    in_library = world > 1 and backend == "nccl"
+    if in_library:
+        uid = [api.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        r.comm_init(world, rank, uid[0])
+
     def exchange():
         if world > 1:
-            if by_tiles:
+            if in_library:
+                r.gather_tiles(0) if by_tiles else r.reduce(0)
+                r.sync()
+            elif by_tiles:
                 rdist.gather_owned_tiles(fb, rank, world, dst=0)
             else:
                 rdist.reduce_framebuffer(fb, dst=0)
@@ -254,7 +267,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": label, "width": WIDTH, "height": HEIGHT,
-                       "spp": SPP, "frames_per_launch": F, "launches_per_step": len(launches), "triangles": scene.n_triangles,
+                       "spp": SPP, "frames_per_launch": F, "launches_per_step": len(launches), "triangles": n_triangles,
                        "step": "one whole job: clear the image, render every frame, wait for the last launch" + (", exchange" if world > 1 else ""),
                        "sharding": (f"32x32 tiles round-robin over {n_gpus} GPU(s) + RCCL gather of owned tiles" if by_tiles else
                                     f"{SPP} frames in {n_gpus} contiguous block(s), one per GPU, + RCCL reduce of the partial images"),
@@ -281,7 +294,7 @@ def main():
                 if name == head:
                     continue
                 sc = mk()
-                pk = sc.to_desc()
+                pk = sc if hasattr(sc, "byref") else sc.to_desc()
                 bpr = algorithmic_bytes_per_ray(pk, api, abi, local, frames=2)
                 with api.Renderer(pk, device=local, flags=overlap) as rr:
                     rr.tune(fpl)
@@ -299,7 +312,7 @@ def main():
                 rl2 = rooflines(name, s2.rays / dt, cus, bpr)
                 out["configs"][name] = {
                     "workload": lab, "width": pk.xres, "height": pk.yres, "spp": spp, "frames_per_launch": fpl,
-                    "triangles": sc.n_triangles, "rays": s2.rays, "rays_per_path": s2.rays / max(1, s2.paths),
+                    "triangles": api.pack_info(pk).n_triangles, "rays": s2.rays, "rays_per_path": s2.rays / max(1, s2.paths),
                     "value": s2.rays / dt / 1e6, "unit": "Mrays/s", "seconds": dt, "ms_per_frame": dt / spp * 1e3,
                     "launch_ms": s2.kernel_ms / max(1, s2.launches), "launch_period_ms": dt * 1e3 / max(1, s2.launches),
                     "kernel": (pmc_per_ray(name) or {}).get("kernel"),

@@ -207,9 +207,27 @@ int main(int argc, char** argv) {
   std::fprintf(stderr, "\n");
   const double render_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_render).count();
 
+  // The exchange step of a multi-GPU render: every GPU sends the 32x32 tiles it owns to GPU 0 over xGMI (RCCL inside
+  // the library, rene_gather_tiles; one process, one communicator over the `gpus` contexts).  Only where RCCL is
+  // missing do the per-GPU images meet on the host instead.
+  bool gathered = false;
+  if (gpus > 1) {
+    if (rene_comm_init_all(ctx.data(), (int)gpus) == RENE_OK) {
+      bool ok = rene_comm_group_begin() == RENE_OK;
+      for (uint32_t g = 0; g < gpus && ok; ++g) ok = rene_gather_tiles(ctx[g], 0) == RENE_OK;
+      ok = rene_comm_group_end() == RENE_OK && ok;
+      if (!ok) return die("rene_gather_tiles");
+      for (uint32_t g = 0; g < gpus; ++g)
+        if (rene_sync(ctx[g]) != RENE_OK) return die("rene_sync");
+      gathered = true;
+    } else {
+      std::fprintf(stderr, "WARN %s -- summing the per-GPU images on the host\n", rene_last_error());
+    }
+  }
   const size_t n_px = (size_t)desc.xresolution * desc.yresolution;
   auto layer = [&](int l, std::vector<float>& sum) -> bool {
     sum.assign(n_px * 3, 0.0f);
+    if (gathered || gpus == 1) return rene_download(ctx[0], l, 3, sum.data(), sum.size()) == RENE_OK;
     std::vector<float> part(n_px * 3);
     for (uint32_t g = 0; g < gpus; ++g) {
       if (rene_download(ctx[g], l, 3, part.data(), part.size()) != RENE_OK) return false;
