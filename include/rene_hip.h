@@ -195,6 +195,11 @@ enum {
   RENE_FLAG_DYNAMIC_FIRST = 1u << 5, /* accepted and ignored: every work batch comes from the atomic counter (a statically owned
                                         first batch made a launch depend on all of its waves being resident) */
   RENE_FLAG_WAVEFRONT = 1u << 6, /* BVH scenes: the stage-separated wavefront integrator (wavefront.inc) instead of the traversal-restart megakernel */
+  RENE_FLAG_FP16_PAYLOAD = 1u << 8, /* with RENE_FLAG_WAVEFRONT: a path slot keeps its ray direction and throughput as fp16 (BASELINE config 5's
+                                       "fp16 ray payload"): 100 instead of 116 bytes per slot and round trip; origin, distances, sums and
+                                       random streams stay fp32 / u32.  The image then differs from the fp32 payload's within the
+                                       tolerance tests/test_gpu_scenes.py states; ignored by the default integrators, whose ray
+                                       payload never leaves the registers */
   RENE_FLAG_OVERLAP = 1u << 7 /* consecutive rene_render launches alternate between two streams so that one starts while the
                                  previous drains its longest paths; per-pixel ordering is kept on the device (bit-identical
                                  images); rene_sync / rene_download / rene_get_stats / rene_framebuffer join both streams */

@@ -35,6 +35,8 @@ struct WaveState {
   unsigned long long* wave_sums;  // [waves][8] per-wave counter rows (folded into the context's counters at the end)
   uint32_t n_slots;
   uint32_t max_lights;
+  uint32_t fp16_payload;  // RENE_FLAG_FP16_PAYLOAD: direction and throughput of a slot as six halves in ONE float4 (Q.rd), Q.color unused
+  uint32_t pad_;
 };
 hipError_t launch_wave_init(const WaveState& Q, hipStream_t st);
 hipError_t launch_wave_finish(const RenderParams& P, const WaveState& Q, hipStream_t st);

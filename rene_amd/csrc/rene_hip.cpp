@@ -565,6 +565,7 @@ static int rene_create_impl(const rene_scene_desc* scene, const rene_opts* opts,
     rene::WaveState& q = c->wave;
     q.n_slots = c->n_work;
     q.max_lights = (uint32_t)ps.lights.size();
+    q.fp16_payload = (o.flags & RENE_FLAG_FP16_PAYLOAD) ? 1u : 0u;
     const size_t n = q.n_slots;
     auto dev = [&](void** p, size_t bytes) {
       hipError_t e = hipMalloc(p, std::max<size_t>(16, bytes));

@@ -277,3 +277,32 @@ def test_full_size_configs_hold_their_invariants(name):
     for k in ("rays_closest", "rays_shadow", "hits", "adds"):  # per path, within a few per cent of the small render
         a, b = st[k] / st["paths"], ss[k] / ss["paths"]
         assert abs(a - b) <= 0.06 * max(b, 1e-9) + 1e-3, (k, a, b)
+
+
+def test_wavefront_fp16_ray_payload(oracle_mod):
+    """BASELINE config 5's "fp16 ray payload" (RENE_FLAG_FP16_PAYLOAD with RENE_FLAG_WAVEFRONT): a slot's ray direction and
+    throughput travel as halves.  Same counters up to path forks, and an image within the T1 tolerance of the fp32
+    payload's *in the mean* (relMSE <= 1e-3; a direction rounded to 11 bits moves a hit point by up to 1e-3 of its distance, so
+    single pixels at edges may differ); the oracle is the third party."""
+    s = scenes.teapot_class(160, 90, n_lat=40, n_lon=42)
+    frames = 16
+    imgs, stats = {}, {}
+    for name, flags in (("fp32", abi.FLAG_WAVEFRONT), ("fp16", abi.FLAG_WAVEFRONT | abi.FLAG_FP16_PAYLOAD)):
+        with api.Renderer(s, flags=flags | abi.FLAG_COUNTERS) as r:
+            r.render(0, frames)
+            imgs[name] = r.download(0)
+            stats[name] = r.stats().as_dict()
+    assert not np.array_equal(imgs["fp16"], imgs["fp32"])  # the flag does something
+    for k in ("rays_closest", "hits", "adds"):
+        assert abs(stats["fp16"][k] - stats["fp32"][k]) <= 5e-3 * stats["fp32"][k], (k, stats["fp16"][k], stats["fp32"][k])
+    a, b = imgs["fp16"], imgs["fp32"]
+    assert np.isfinite(a).all()
+    assert float(((a - b) ** 2).sum() / (b ** 2).sum()) <= 1e-3 and abs(float(a.sum() / b.sum()) - 1) < 2e-3
+    o = oracle_mod.Oracle(s)
+    o.render(0, frames)
+    ref = o.download(0)
+    assert float(((a - ref) ** 2).sum() / (ref ** 2).sum()) <= 2e-3
+    # the default integrators keep their payload in registers: the flag changes nothing there
+    with api.Renderer(s) as r0, api.Renderer(s, flags=abi.FLAG_FP16_PAYLOAD) as r1:
+        r0.render(0, 4); r1.render(0, 4)
+        assert np.array_equal(r0.download(0), r1.download(0))
