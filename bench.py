@@ -176,9 +176,20 @@ def main():
     # RENE_DIST_BACKEND=gloo (several ranks on one GPU, which RCCL refuses) the torch-level exchange of rene_amd.dist stands in.
     in_library = world > 1 and backend == "nccl"
     if in_library:
-        uid = [api.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        r.comm_init(world, rank, uid[0])
+        # every rank must end up on the same path, and ncclCommInitRank blocks until all ranks have called it: first agree
+        # that RCCL loads everywhere (rene_comm_unique_id touches nothing but the library), then set the communicator up
+        ok = torch.ones(1, device=f"cuda:{local}")
+        try:
+            my_uid = api.comm_unique_id()
+        except Exception as e:  # RCCL missing: the torch-level exchange of rene_amd.dist stands in (and the line says so)
+            print(f"[bench] rank {rank}: exchange inside the library unavailable ({e}); using torch.distributed", file=sys.stderr, flush=True)
+            ok.zero_()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        in_library = bool(ok.item() > 0)
+        if in_library:
+            uid = [my_uid if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            r.comm_init(world, rank, uid[0])
 
     def exchange():
         if world > 1:
@@ -271,6 +282,8 @@ def main():
                        "step": "one whole job: clear the image, render every frame, wait for the last launch" + (", exchange" if world > 1 else ""),
                        "sharding": (f"32x32 tiles round-robin over {n_gpus} GPU(s) + RCCL gather of owned tiles" if by_tiles else
                                     f"{SPP} frames in {n_gpus} contiguous block(s), one per GPU, + RCCL reduce of the partial images"),
+                       "exchange": ("none (one GPU)" if world == 1 else "rene_reduce / rene_gather_tiles (RCCL inside librene_hip)" if in_library
+                                    else f"torch.distributed ({backend}) on the framebuffer tensor"),
                        "seed": abi.DEFAULT_SEED},
             "rays": total_rays, "rays_per_path": total_rays / (WIDTH * HEIGHT * SPP * K),
             "jobs_bit_identical": identical,
