@@ -587,7 +587,7 @@ static int rene_create_impl(const rene_scene_desc* scene, const rene_opts* opts,
   }
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_work_counters), rene_ctx::kCounters * sizeof(uint32_t)));
   HIP_TRY(hipMemsetAsync(c->d_work_counters, 0, rene_ctx::kCounters * sizeof(uint32_t), c->stream));
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_counters), 16 * sizeof(unsigned long long)));
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_counters), 24 * sizeof(unsigned long long)));
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_item_done), std::max<size_t>(1, c->n_work) * sizeof(uint32_t)));
   HIP_TRY(hipMemsetAsync(c->d_item_done, 0, std::max<size_t>(1, c->n_work) * sizeof(uint32_t), c->stream));
   if ((o.flags & RENE_FLAG_OVERLAP) && !c->wavefront) {
@@ -598,7 +598,7 @@ static int rene_create_impl(const rene_scene_desc* scene, const rene_opts* opts,
     std::memset(c->h_resident, 0, c->resident_words * sizeof(uint32_t));
   }
   HIP_TRY(hipMemsetAsync(c->fb, 0, c->fb_floats * sizeof(float), c->stream));  // main.rs:1229-1237
-  HIP_TRY(hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream));
+  HIP_TRY(hipMemsetAsync(c->d_counters, 0, 24 * sizeof(unsigned long long), c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
 
   if (c->h_upload) {
@@ -809,7 +809,7 @@ int rene_reset(rene_ctx* c) {
   c->handoff_failed = false;  // the counters are cleared below and the image starts again from zero
   c->exchanged = false;
   HIP_TRY(hipMemsetAsync(c->fb, 0, c->fb_floats * sizeof(float), c->stream));
-  HIP_TRY(hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream));
+  HIP_TRY(hipMemsetAsync(c->d_counters, 0, 24 * sizeof(unsigned long long), c->stream));
   HIP_TRY(hipMemsetAsync(c->d_item_done, 0, std::max<size_t>(1, c->n_work) * sizeof(uint32_t), c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->prev_final = 0;  // the pixel records carry version 0 again
@@ -897,8 +897,15 @@ int rene_get_stats(rene_ctx* c, rene_stats* out) {
   HIP_TRY(hipSetDevice(c->device));
   int rc = c->drain();
   if (rc != RENE_OK) return rc;
-  unsigned long long h[9];
+  unsigned long long h[24];
   HIP_TRY(hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
+  if (std::getenv("RENE_DEBUG") && h[12])  // RENE_FLAG_COUNTERS on the traversal-restart kernel: lanes active per step kind
+    std::fprintf(stderr, "[rene] steps (wave executions, lanes, lanes / 64 per execution): node %llu %llu %.3f | leaf %llu %llu %.3f | logic %llu %llu %.3f | iterations %llu\n",
+                 h[12], h[6], (double)h[6] / (64.0 * (double)h[12]), h[13], h[16], (double)h[16] / (64.0 * (double)std::max(1ull, h[13])), h[14], h[15],
+                 (double)h[15] / (64.0 * (double)std::max(1ull, h[14])), h[17]);
+  if (std::getenv("RENE_DEBUG") && h[12])
+    std::fprintf(stderr, "[rene] node visits %llu: nothing hit %llu (%.3f), reached by a pop %llu (%.3f), both %llu (%.3f); deepest stack %llu entries\n", h[6], h[18],
+                 (double)h[18] / (double)h[6], h[19], (double)h[19] / (double)h[6], h[20], (double)h[20] / (double)h[6], h[21]);
   std::memset(out, 0, sizeof(*out));
   out->rays_closest = h[0];
   out->rays_shadow = h[1];
