@@ -12,13 +12,15 @@ steps are K jobs back to back, each timed on its own as well: `step_ms_median` /
 same frames, so its image must be bit-identical to the first one's -- checked after the timed region.  Inputs (scene tables,
 BVH, frame seeds) are resident in HBM before the timed region; `value` = rays of all K jobs / elapsed.
 
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL).  Strong scaling: the job is still 1024 spp
-of the whole image; its frames are dealt to the ranks in N contiguous blocks (rene_amd.dist.frame_block), each rank
-renders its block in at least two launches, ranks never talk while rendering, and the one exchange step of a job -- an
-RCCL reduce (sum) of the [3][H][W][4] f32 partial images onto rank 0 -- is inside the job, hence inside the timed
-region.  RENE_BENCH_SHARD=tiles selects north_star's cut (32x32 tiles round-robin + a gather of owned tiles:
-bit-identical to one GPU, but a rank's launches shrink with N; DESIGN.md section 6 has the measurement behind
-the default).  value = rays of all ranks / max-over-ranks time.
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL).  Weak scaling (per-GPU work fixed): the job
+becomes an N x 1024 spp image; its frames are dealt to the ranks in N contiguous blocks of 1024
+(rene_amd.dist.frame_block), every rank renders its block exactly as a single GPU renders the headline job, ranks
+never talk while rendering, and the one exchange step of a job -- an RCCL reduce (sum) of the [3][H][W][4] f32 partial
+images onto rank 0 -- is inside the job, hence inside the timed region.  RENE_BENCH_SCALING=strong keeps the job at
+1024 spp (128 frames per rank at N = 8: the fixed costs of a 6 ms share then show); RENE_BENCH_SHARD=tiles selects
+north_star's cut (32x32 tiles round-robin + a gather of owned tiles: bit-identical to one GPU, but a rank's launches
+shrink with N; DESIGN.md section 6 has the measurement behind the default).  value = rays of all ranks /
+max-over-ranks time.
 
 The JSON line also carries
   roofline     -- for the dominant kernel of the headline job.  The kernel is bound by VALU issue, not by HBM (the
@@ -152,6 +154,11 @@ def main():
     n_triangles = api.pack_info(packed).n_triangles
 
     by_tiles = os.environ.get("RENE_BENCH_SHARD", "frames") == "tiles"
+    # N > 1, default: weak scaling -- every GPU renders the headline job's 1024 frames of the whole image (its own frame
+    # range: the job is an N x 1024 spp image), then one reduce.  RENE_BENCH_SCALING=strong keeps the job at 1024 spp and
+    # deals its frames out; the tile cut shrinks a rank's share by construction, so it is always strong.
+    weak = world > 1 and not by_tiles and os.environ.get("RENE_BENCH_SCALING", "weak") != "strong"
+    JOB_SPP = SPP * world if weak else SPP
     t_rank, t_world = (rank, world) if by_tiles else (0, 1)
     shard = dict(shard_mode=abi.SHARD_TILES, shard_rank=t_rank, shard_count=t_world)
     fb = torch.zeros((3, HEIGHT, WIDTH, 4), dtype=torch.float32, device=f"cuda:{local}")
@@ -163,7 +170,7 @@ def main():
     if by_tiles:
         launches = [(f0, min(F, SPP - f0)) for f0 in range(0, SPP, F)]
     else:
-        lo, hi = rdist.frame_block(rank, world, SPP)
+        lo, hi = rdist.frame_block(rank, world, JOB_SPP)
         launches = [(f0, min(F, hi - f0)) for f0 in range(lo, hi, F)]
         if len(launches) == 1 and launches[0][1] >= 2:
             # a block that fits one launch is rendered as two: the second starts while the first finishes its longest
@@ -274,18 +281,18 @@ def main():
             "metric": "Mrays/s", "value": rate / 1e6, "unit": "Mrays/s",
             "n_gpus": n_gpus, "steps": K, "warmup": Wm, "ms_per_step": elapsed / K * 1e3,
             "step_ms_median": statistics.median(step_ms), "step_ms_min": min(step_ms),
-            "ms_per_frame": elapsed / (K * SPP) * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ms_per_frame": elapsed / (K * JOB_SPP) * 1e3,
+            "higher_is_better": True, "scaling": "weak" if (weak or world == 1) else "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": label, "width": WIDTH, "height": HEIGHT,
-                       "spp": SPP, "frames_per_launch": F, "launches_per_step": len(launches), "triangles": n_triangles,
+                       "spp": JOB_SPP, "spp_per_gpu": JOB_SPP // n_gpus if not by_tiles else JOB_SPP, "frames_per_launch": F, "launches_per_step": len(launches), "triangles": n_triangles,
                        "step": "one whole job: clear the image, render every frame, wait for the last launch" + (", exchange" if world > 1 else ""),
                        "sharding": (f"32x32 tiles round-robin over {n_gpus} GPU(s) + RCCL gather of owned tiles" if by_tiles else
-                                    f"{SPP} frames in {n_gpus} contiguous block(s), one per GPU, + RCCL reduce of the partial images"),
+                                    f"{JOB_SPP} frames in {n_gpus} contiguous block(s), one per GPU, + RCCL reduce of the partial images"),
                        "exchange": ("none (one GPU)" if world == 1 else "rene_reduce / rene_gather_tiles (RCCL inside librene_hip)" if in_library
                                     else f"torch.distributed ({backend}) on the framebuffer tensor"),
                        "seed": abi.DEFAULT_SEED},
-            "rays": total_rays, "rays_per_path": total_rays / (WIDTH * HEIGHT * SPP * K),
+            "rays": total_rays, "rays_per_path": total_rays / (WIDTH * HEIGHT * JOB_SPP * K),
             "jobs_bit_identical": identical,
             "roofline": {"bound": "valu", "achieved": valu["achieved"], "peak": valu["peak"], "unit": valu["unit"],
                          "frac": valu["frac"], "traffic": traffic,
