@@ -16,10 +16,11 @@ namespace rene {
 // ---- BVH4 node with 8-bit child boxes: 4 x float4 = one 64-byte line for four children ----------------------
 // (a traversal step costs four divergent 16-byte loads whatever it fetches -- measured: the texture
 // addresser is the busiest unit of the BVH kernels -- so a line should carry as many children as it can)
-//   q0 = origin.x origin.y origin.z bits(ex | ey << 8 | ez << 16)   step_a = 2^(e_a - 127); corner = origin + byte * step
+//   q0 = origin.x origin.y origin.z step.z        step_a = 2^e_a, the smallest power of two with 255 steps >= the extent;
+//                                                  corner = origin + byte * step
 //   q1 = bits(child0) bits(child1) bits(child2) bits(child3)
 //   q2 = bits(lo.x of children 0..3, one byte each) bits(lo.y ...) bits(lo.z ...) bits(hi.x ...)
-//   q3 = bits(hi.y ...) bits(hi.z ...) 0 0
+//   q3 = bits(hi.y ...) bits(hi.z ...) step.x step.y
 // lo is rounded down and hi up, so the decoded box contains the exact one; an absent child has lo = 255 > hi = 0.
 // child word: bit31 = 0 -> inner node index
 //             bit31 = 1 -> leaf: bit30 = sphere leaf, bits29..26 = count-1, bits25..0 = first slot

@@ -293,7 +293,7 @@ struct Collapse4 {
     uint8_t qlo[3][4], qhi[3][4];
     for (int a = 0; a < 3; ++a)
       for (int c = 0; c < 4; ++c) { qlo[a][c] = 255; qhi[a][c] = 0; }  // lo > hi: never hit
-    uint32_t ebytes = 0;
+    float scale[3] = {0, 0, 0};  // 2^e per axis, as floats (the traversal multiplies by them; decoding exponent bytes cost six instructions a node)
     float origin[3] = {0, 0, 0};
     if (!ch.empty()) {
       for (int a = 0; a < 3; ++a) {
@@ -308,7 +308,7 @@ struct Collapse4 {
           e = std::max(-126, std::min(127, ex));
         }
         const double step = std::ldexp(1.0, e);
-        ebytes |= (uint32_t)(e + 127) << (8 * a);
+        scale[a] = (float)step;  // 2^e, e in [-126, 127]: a normal float, exact
         for (size_t c = 0; c < ch.size(); ++c) {
           double l = std::floor((ch[c].box.lo[a] - lo) / step), h = std::ceil((ch[c].box.hi[a] - lo) / step);
           qlo[a][c] = (uint8_t)std::max(0.0, std::min(255.0, l));
@@ -318,7 +318,9 @@ struct Collapse4 {
       for (size_t c = 0; c < ch.size(); ++c) words[c] = ch[c].word;
     }
     n.q[0] = origin[0]; n.q[1] = origin[1]; n.q[2] = origin[2];
-    n.q[3] = bits_to_float(ebytes);
+    n.q[3] = scale[2];
+    n.q[14] = scale[0];
+    n.q[15] = scale[1];
     for (int c = 0; c < 4; ++c) n.q[4 + c] = bits_to_float(words[c]);
     for (int a = 0; a < 3; ++a) {
       n.q[8 + a] = bits_to_float(qlo[a][0] | (qlo[a][1] << 8) | (qlo[a][2] << 16) | ((uint32_t)qlo[a][3] << 24));
