@@ -27,6 +27,7 @@ namespace rene {
 struct Node {
   float q[16];
 };
+constexpr uint32_t TOP_NODES_MAX = 341;  // 1 + 4 + 16 + 64 + 256: the top levels the builder stores first, breadth-first (21.8 KB)
 constexpr uint32_t LEAF_BIT = 0x80000000u;
 constexpr uint32_t SPHERE_BIT = 0x40000000u;
 constexpr uint32_t LEAF_COUNT_SHIFT = 26;
@@ -178,7 +179,7 @@ struct Accel {
   uint32_t n_nodes;
   uint32_t n_slots;
   uint32_t n_items;
-  uint32_t pad;
+  uint32_t n_top;          // nodes [0, n_top) are the tree's top levels, breadth-first (TOP_NODES_MAX)
 };
 
 // Uniform, rene-shader/src/lib.rs:90-102: kept in memory rather than in the kernel arguments -- 52

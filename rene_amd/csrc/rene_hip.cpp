@@ -470,6 +470,8 @@ static int rene_create_impl(const rene_scene_desc* scene, const rene_opts* opts,
   UP(ps.emit.isect, v.emit.isect);
   UP(ps.main.items, v.main.items);
   UP(ps.emit.items, v.emit.items);
+  v.main.n_top = ps.main.n_top;
+  v.emit.n_top = ps.emit.n_top;
   v.main.n_items = ps.main.n_loop;  // the loop's items; the auxiliary records of box items follow them
   v.emit.n_items = ps.emit.n_loop;
   v.main.n_nodes = (uint32_t)ps.main.nodes.size();
@@ -904,8 +906,8 @@ int rene_get_stats(rene_ctx* c, rene_stats* out) {
                  h[12], h[6], (double)h[6] / (64.0 * (double)h[12]), h[13], h[16], (double)h[16] / (64.0 * (double)std::max(1ull, h[13])), h[14], h[15],
                  (double)h[15] / (64.0 * (double)std::max(1ull, h[14])), h[17]);
   if (std::getenv("RENE_DEBUG") && h[12])
-    std::fprintf(stderr, "[rene] node visits %llu: nothing hit %llu (%.3f), reached by a pop %llu (%.3f), both %llu (%.3f); deepest stack %llu entries\n", h[6], h[18],
-                 (double)h[18] / (double)h[6], h[19], (double)h[19] / (double)h[6], h[20], (double)h[20] / (double)h[6], h[21]);
+    std::fprintf(stderr, "[rene] node visits %llu: nothing hit %llu (%.3f), reached by a pop %llu (%.3f), both %llu (%.3f); in the top levels %llu (%.3f); deepest stack %llu entries\n", h[6], h[18],
+                 (double)h[18] / (double)h[6], h[19], (double)h[19] / (double)h[6], h[20], (double)h[20] / (double)h[6], h[22], (double)h[22] / (double)h[6], h[21]);
   std::memset(out, 0, sizeof(*out));
   out->rays_closest = h[0];
   out->rays_shadow = h[1];

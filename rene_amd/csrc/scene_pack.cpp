@@ -635,6 +635,42 @@ void finish_accel(const std::vector<Prim>& prims, uint32_t max_leaf, BuiltAccel&
   Collapse4 wide(b.nodes);
   out.depth = wide.run();
   out.nodes = std::move(wide.out);
+  // The tree's top levels first, in breadth-first order (every ray starts there): nodes [0, n_top) are whole levels, at
+  // most TOP_NODES_MAX of them; the rest keep their depth-first order.  Inner child words are renumbered to match.
+  {
+    const size_t n = out.nodes.size();
+    std::vector<uint32_t> fresh(n, 0xffffffffu), bfs;
+    std::vector<uint32_t> level{0u};
+    auto inner_children = [&](uint32_t i, std::vector<uint32_t>& to) {
+      for (int c = 0; c < 4; ++c) {
+        const uint32_t w = float_bits(out.nodes[i].q[4 + c]);
+        if (!(w & LEAF_BIT)) to.push_back(w);
+      }
+    };
+    while (!level.empty() && bfs.size() + level.size() <= TOP_NODES_MAX) {
+      std::vector<uint32_t> next;
+      for (uint32_t i : level) {
+        fresh[i] = (uint32_t)bfs.size();
+        bfs.push_back(i);
+        inner_children(i, next);
+      }
+      level.swap(next);
+    }
+    out.n_top = (uint32_t)bfs.size();
+    uint32_t k = out.n_top;
+    for (size_t i = 0; i < n; ++i)
+      if (fresh[i] == 0xffffffffu) fresh[i] = k++;
+    std::vector<Node> moved(n);
+    for (size_t i = 0; i < n; ++i) {
+      Node nd = out.nodes[i];
+      for (int c = 0; c < 4; ++c) {
+        const uint32_t w = float_bits(nd.q[4 + c]);
+        if (!(w & LEAF_BIT)) nd.q[4 + c] = bits_to_float(fresh[w]);
+      }
+      moved[fresh[i]] = nd;
+    }
+    out.nodes.swap(moved);
+  }
   out.isect.resize(prims.size());
   for (size_t s = 0; s < prims.size(); ++s) out.isect[s] = prims[b.order[s]].isect;
   order = std::move(b.order);

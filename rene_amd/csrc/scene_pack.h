@@ -16,6 +16,7 @@ struct BuiltAccel {
   std::vector<SmallItem> items;  // small-scene item list (empty if the structure is too large): n_loop items the
                                  // wave-coherent loop visits, then one auxiliary record per box item
   uint32_t n_loop = 0;
+  uint32_t n_top = 0;            // nodes [0, n_top): the tree's top levels in breadth-first order (whole levels, <= TOP_NODES_MAX)
   uint32_t depth = 0;            // max stack depth a traversal can need
 };
 
