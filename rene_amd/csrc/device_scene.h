@@ -72,6 +72,14 @@ struct Inst {
   uint32_t material_type;  // copy of materials[material].type
   float kd[4];             // Matte + Solid texture shortcut: albedo; .w = 1 if the shortcut is valid
   float emit[4];           // area light radiance; .w = 1 if area light is non-null
+  // A single-lobe general material (Glass, Substrate, Metal, Mirror) whose textures are all Solid, resolved at upload like
+  // the Matte shortcut: compute_bsdf then needs neither the material record nor its texture records (two dependent
+  // rounds of loads per bounce).  res_type = RENE_MATERIAL_* or 0 (not resolved: the general path runs).
+  uint32_t res_type;
+  uint32_t res_remap;      // Substrate / Metal: remap_roughness
+  float res_ru, res_rv;    // Substrate / Metal: uroughness.x, vroughness.x as stored (the remap stays on the device)
+  float res_c0[4];         // Substrate Kd | Metal eta | Mirror Kr | Glass ir 0 0
+  float res_c1[4];         // Substrate Ks | Metal k
 };
 
 // ---- emit objects (EnumSurfaceSample, surface_sample.rs:20-33) --------------------------------------
@@ -161,7 +169,7 @@ constexpr float SMALL_KIND_QUAD = 0.0f, SMALL_KIND_TRIANGLE = 1.0f, SMALL_KIND_S
 //   byte 0                   main structure's items + auxiliary records (copy of Accel::items), 64 B each:
 //                            the (item, s, r) -> (slot, u, v) mapping after the item loop
 //   small_off[SMALL_OFF_EMIT_ITEMS]  the emitter structure's items
-//   small_off[SMALL_OFF_HIT]   per main slot, 160 B: PrimIsect (48) | PrimShade (64) | the slot's Inst (48)
+//   small_off[SMALL_OFF_HIT]   per main slot, 208 B: PrimIsect (48) | PrimShade (64) | the slot's Inst (96)
 //   small_off[SMALL_OFF_EMIT]  per emitter slot, 80 B: PrimIsect (48) | EmitPdf (16) | primitive_count 0 0 0
 //   small_off[SMALL_OFF_EOBJ]  EmitObject[] (64 B each)
 //   small_off[SMALL_OFF_ETRI]  EmitTri[] (48 B each)
@@ -169,7 +177,7 @@ constexpr float SMALL_KIND_QUAD = 0.0f, SMALL_KIND_TRIANGLE = 1.0f, SMALL_KIND_S
 constexpr uint32_t SMALL_LDS_MAX_BYTES = 22u * 1024u;  // six workgroups per CU keep image + frame seeds in 160 KB of LDS
 constexpr uint32_t SMALL_LDS_MAX_SEEDS = 1024u;        // a launch's frame seeds follow the image in LDS when it has at most this many frames
 enum : uint32_t { SMALL_OFF_EMIT_ITEMS = 0, SMALL_OFF_HIT, SMALL_OFF_EMIT, SMALL_OFF_EOBJ, SMALL_OFF_ETRI, SMALL_OFF_COUNT };
-constexpr uint32_t SMALL_HIT_FLOATS = 40, SMALL_EMIT_FLOATS = 20;
+constexpr uint32_t SMALL_HIT_FLOATS = 52, SMALL_EMIT_FLOATS = 20;
 
 // one traversable structure
 struct Accel {

@@ -44,7 +44,7 @@ hipError_t launch_wave_rounds(const LaunchConfig& cfg, const SceneView& S, const
                               uint32_t rounds, hipStream_t st);
 hipError_t launch_trace(const LaunchConfig& cfg, const SceneView& S, int which, uint32_t n, const float* o,
                         const float* d, float tmin, float tmax, rene_hit* out, hipStream_t st);
-hipError_t launch_bsdf_eval(const SceneView& S, uint32_t material, uint32_t n, const float* nrm3, const float* uv,
+hipError_t launch_bsdf_eval(const SceneView& S, uint32_t material, int inst_index, uint32_t n, const float* nrm3, const float* uv,
                             const float* wo3, const float* wi3, const uint32_t* seeds, float* out, hipStream_t st);
 hipError_t launch_medium_eval(const SceneView& S, uint32_t medium, uint32_t n, const float* rd3, const float* t_max,
                               const float* wo3, const float* wi3, const uint32_t* seeds, float* out, hipStream_t st);

@@ -99,19 +99,24 @@ hipError_t launch_pack_tiles(const float* fb, float* packed, uint32_t width, uin
 // the integrator does and returns f(wo,wi), pdf(wo,wi) and one sample_f(wo) drawn from
 // PCG32si::new(seed).  out[12] = f.xyz, pdf, s.wi.xyz, s.f.xyz, s.pdf, len
 // -------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) bsdf_eval_kernel(SceneView S, uint32_t material, uint32_t n, const float* nrm3,
+__global__ void __launch_bounds__(64) bsdf_eval_kernel(SceneView S, uint32_t material, int inst_index, uint32_t n, const float* nrm3,
                                                        const float* uv2_, const float* wo3, const float* wi3,
                                                        const uint32_t* seeds, float* out) {
   constexpr uint32_t ALL = FEAT_SPHERES | FEAT_GENERAL_BSDF | FEAT_TEXTURES | FEAT_LIGHTS | FEAT_BACKGROUND | FEAT_MULTI_LOBE;
   uint32_t i = blockIdx.x * 64 + threadIdx.x;
   if (i >= n) return;
   Inst inst;
-  inst.material = material;
-  inst.area_light = 0;
-  inst.primitive_count = 1.0f;
-  inst.material_type = S.materials[material].type;
-  inst.kd[0] = inst.kd[1] = inst.kd[2] = inst.kd[3] = 0.0f;
-  inst.emit[0] = inst.emit[1] = inst.emit[2] = inst.emit[3] = 0.0f;
+  if (inst_index >= 0) {
+    inst = S.insts[inst_index];
+  } else {
+    inst.material = material;
+    inst.area_light = 0;
+    inst.primitive_count = 1.0f;
+    inst.material_type = S.materials[material].type;
+    inst.kd[0] = inst.kd[1] = inst.kd[2] = inst.kd[3] = 0.0f;
+    inst.emit[0] = inst.emit[1] = inst.emit[2] = inst.emit[3] = 0.0f;
+    inst.res_type = 0u;
+  }
   f3 normal = normalize(mk3(nrm3[3 * i], nrm3[3 * i + 1], nrm3[3 * i + 2]));
   Bsdf<5> b;
   b.len = 0;
@@ -131,9 +136,9 @@ __global__ void __launch_bounds__(64) bsdf_eval_kernel(SceneView S, uint32_t mat
   o[7] = sf.f.x; o[8] = sf.f.y; o[9] = sf.f.z; o[10] = sf.pdf; o[11] = (float)b.len;
 }
 
-hipError_t launch_bsdf_eval(const SceneView& S, uint32_t material, uint32_t n, const float* nrm3, const float* uv,
+hipError_t launch_bsdf_eval(const SceneView& S, uint32_t material, int inst_index, uint32_t n, const float* nrm3, const float* uv,
                             const float* wo3, const float* wi3, const uint32_t* seeds, float* out, hipStream_t st) {
-  hipLaunchKernelGGL(bsdf_eval_kernel, dim3((n + 63) / 64), dim3(64), 0, st, S, material, n, nrm3, uv, wo3, wi3, seeds, out);
+  hipLaunchKernelGGL(bsdf_eval_kernel, dim3((n + 63) / 64), dim3(64), 0, st, S, material, inst_index, n, nrm3, uv, wo3, wi3, seeds, out);
   return hipGetLastError();
 }
 

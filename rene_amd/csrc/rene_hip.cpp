@@ -167,6 +167,7 @@ struct rene_ctx {
   // bookkeeping (teapot-class 6.8 -> 6.7)
   static constexpr uint32_t kWholeLaunch = 0xffffffffu;
   uint32_t item_frames = 0;
+  std::vector<uint32_t> inst_material;  // material index of every instance (rene_bsdf_eval looks an instance of its material up)
   uint32_t* d_item_done = nullptr;  // [n_work] versions, traversal-restart kernels only (device_code.inc, item_flag_publish)
   unsigned long long* d_counters = nullptr;
   // stage-separated wavefront integrator (BVH scenes): path state in HBM + a pinned word for the host loop
@@ -482,6 +483,8 @@ static int rene_create_impl(const rene_scene_desc* scene, const rene_opts* opts,
   UP(ps.emit_pdf, v.emit_pdf);
   UP(ps.spheres, v.spheres);
   UP(ps.insts, v.insts);
+  c->inst_material.clear();
+  for (const rene::Inst& in : ps.insts) c->inst_material.push_back(in.material);
   UP(ps.emit_objects, v.emit_objects);
   UP(ps.emit_tris, v.emit_tris);
   UP(ps.materials, v.materials);
@@ -968,8 +971,13 @@ int rene_bsdf_eval(rene_ctx* c, uint32_t material_index, size_t n, const float* 
   hipError_t e = hipSuccess;
   for (int i = 0; i < 6 && e == hipSuccess; ++i) e = hipMalloc(&d[i], sizes[i]);
   for (int i = 0; i < 5 && e == hipSuccess; ++i) e = hipMemcpyAsync(d[i], src[i], sizes[i], hipMemcpyHostToDevice, c->stream);
+  // the first instance that uses the material lends its record, so that the probe runs what a render runs (the material
+  // resolved at upload, Inst::res_*); a material no instance uses goes through the material / texture tables
+  int inst_index = -1;
+  for (size_t k = 0; k < c->inst_material.size() && inst_index < 0; ++k)
+    if (c->inst_material[k] == material_index) inst_index = (int)k;
   if (e == hipSuccess)
-    e = rene::launch_bsdf_eval(c->view, material_index, (uint32_t)n, (const float*)d[0], (const float*)d[1],
+    e = rene::launch_bsdf_eval(c->view, material_index, inst_index, (uint32_t)n, (const float*)d[0], (const float*)d[1],
                                (const float*)d[2], (const float*)d[3], (const uint32_t*)d[4], (float*)d[5], c->stream);
   if (e == hipSuccess) e = hipMemcpyAsync(out12, d[5], sizes[5], hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);

@@ -827,6 +827,34 @@ int pack_scene(const rene_scene_desc* d, PackedScene& out, std::string& err) {
       inst.kd[0] = c[0]; inst.kd[1] = c[1]; inst.kd[2] = c[2]; inst.kd[3] = 1.0f;
     }
     if (emitter) { inst.emit[0] = al.v0[0]; inst.emit[1] = al.v0[1]; inst.emit[2] = al.v0[2]; inst.emit[3] = 1.0f; }
+    if (!std::getenv("RENE_NO_RESOLVE")) {  // single-lobe general materials over Solid textures only, resolved here (device_scene.h, Inst::res_*); the knob is for A/B tests
+      auto solid = [&](uint32_t t) { return d->textures[t].type == RENE_TEXTURE_SOLID; };
+      auto rgb = [&](float* dst, uint32_t t) { std::memcpy(dst, d->textures[t].v0, 12); };
+      switch (mat.type) {
+        case RENE_MATERIAL_GLASS:  // material.rs:342-350
+          inst.res_type = mat.type;
+          inst.res_c0[0] = mat.v0[0];
+          break;
+        case RENE_MATERIAL_SUBSTRATE:  // material.rs:188-216: Kd, Ks, uroughness, vroughness
+        case RENE_MATERIAL_METAL:      // material.rs:279-307: eta, k, uroughness, vroughness
+          if (solid(mat.u0[0]) && solid(mat.u0[1]) && solid(mat.u0[2]) && solid(mat.u0[3])) {
+            inst.res_type = mat.type;
+            inst.res_remap = mat.u1[0];
+            rgb(inst.res_c0, mat.u0[0]);
+            rgb(inst.res_c1, mat.u0[1]);
+            inst.res_ru = d->textures[mat.u0[2]].v0[0];
+            inst.res_rv = d->textures[mat.u0[3]].v0[0];
+          }
+          break;
+        case RENE_MATERIAL_MIRROR:  // material.rs:363-373
+          if (solid(mat.u0[0])) {
+            inst.res_type = mat.type;
+            rgb(inst.res_c0, mat.u0[0]);
+          }
+          break;
+        default: break;
+      }
+    }
 
     if (in.shape == RENE_SHAPE_SPHERE) {
       out.features |= FEAT_SPHERES;
@@ -967,8 +995,8 @@ int pack_scene(const rene_scene_desc* d, PackedScene& out, std::string& err) {
       append(out.main.isect[s].q, 12);
       append(out.shade[s].q, 16);
       const Inst& in = out.insts[bits(out.main.isect[s].q[9])];
-      static_assert(sizeof(Inst) == 48, "Inst is three float4");
-      append(reinterpret_cast<const float*>(&in), 12);
+      static_assert(sizeof(Inst) == 96 && SMALL_HIT_FLOATS == 12 + 16 + 24, "Inst is six float4");
+      append(reinterpret_cast<const float*>(&in), 24);
     }
     out.small_off[SMALL_OFF_EMIT] = (uint32_t)(img.size() * 4);
     for (size_t s = 0; s < out.emit.isect.size(); ++s) {

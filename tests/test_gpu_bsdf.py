@@ -5,7 +5,7 @@ the reference's own fp32 formulas (1 - cos^2 cancellation in microfacet.rs:141-1
 import numpy as np
 import pytest
 
-from rene_amd import api, scenes
+from rene_amd import abi, api, scenes
 
 pytestmark = pytest.mark.gpu
 
@@ -92,3 +92,22 @@ def test_veach_metals(oracle_mod):
         assert ok[keep].mean() > frac, (mat, ok[keep].mean())
         s_ok = _close(g[:, 4:7], ref[:, 4:7], 0, atol=5e-3).all(axis=1)  # sampled directions
         assert s_ok[keep].mean() > frac, (mat, "wi", s_ok[keep].mean())
+
+
+def test_materials_resolved_at_upload_render_bit_identically(monkeypatch):
+    """Single-lobe general materials over solid textures are resolved into the instance record when the scene is packed
+    (device_scene.h, Inst::res_*); RENE_NO_RESOLVE sends them through the material / texture tables instead.  Same lobes,
+    so the same image bit for bit -- on the item-loop kernel (zoo, veach-mis) and on the BVH kernels (the same scenes forced)."""
+    for make, flags in ((lambda: scenes.material_zoo(160, 120), 0), (lambda: scenes.material_zoo(160, 120), abi.FLAG_FORCE_BVH),
+                        (lambda: scenes.veach_mis(128, 128), 0), (lambda: scenes.veach_mis(128, 128), abi.FLAG_FORCE_BVH)):
+        images = []
+        for knob in (None, "1"):
+            if knob is None:
+                monkeypatch.delenv("RENE_NO_RESOLVE", raising=False)
+            else:
+                monkeypatch.setenv("RENE_NO_RESOLVE", knob)
+            with api.Renderer(make(), flags=flags) as r:
+                r.render(0, 6)
+                images.append([r.download(l) for l in range(3)])
+        for a, b in zip(*images):
+            assert np.array_equal(a, b)
