@@ -74,13 +74,17 @@ struct Inst {
   float emit[4];           // area light radiance; .w = 1 if area light is non-null
   // A single-lobe general material (Glass, Substrate, Metal, Mirror) whose textures are all Solid, resolved at upload like
   // the Matte shortcut: compute_bsdf then needs neither the material record nor its texture records (two dependent
-  // rounds of loads per bounce).  res_type = RENE_MATERIAL_* or 0 (not resolved: the general path runs).
+  // rounds of loads per bounce).  res_type = RENE_MATERIAL_* or 0 (not resolved: the general path runs), or
+  // INST_RES_MATTE_CHECKER: Matte over a checkerboard of two Solid textures (res_ru / res_rv = uscale / vscale, c0 / c1 = the
+  // colours of the "same parity" / "other parity" squares).
   uint32_t res_type;
   uint32_t res_remap;      // Substrate / Metal: remap_roughness
   float res_ru, res_rv;    // Substrate / Metal: uroughness.x, vroughness.x as stored (the remap stays on the device)
   float res_c0[4];         // Substrate Kd | Metal eta | Mirror Kr | Glass ir 0 0
   float res_c1[4];         // Substrate Ks | Metal k
 };
+
+constexpr uint32_t INST_RES_MATTE_CHECKER = 0x100u;
 
 // ---- emit objects (EnumSurfaceSample, surface_sample.rs:20-33) --------------------------------------
 struct EmitObject {

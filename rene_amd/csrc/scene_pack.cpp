@@ -846,6 +846,17 @@ int pack_scene(const rene_scene_desc* d, PackedScene& out, std::string& err) {
             inst.res_rv = d->textures[mat.u0[3]].v0[0];
           }
           break;
+        case RENE_MATERIAL_MATTE: {  // over a checkerboard of two solid textures (texture.rs:97-118): the teapot scene's floor
+          const rene_texture& t = d->textures[mat.u0[0]];
+          if (t.type == RENE_TEXTURE_CHECKERBOARD && solid(t.u0[0]) && solid(t.u0[1])) {
+            inst.res_type = INST_RES_MATTE_CHECKER;
+            inst.res_ru = t.v0[0];
+            inst.res_rv = t.v0[1];
+            rgb(inst.res_c0, t.u0[0]);
+            rgb(inst.res_c1, t.u0[1]);
+          }
+          break;
+        }
         case RENE_MATERIAL_MIRROR:  // material.rs:363-373
           if (solid(mat.u0[0])) {
             inst.res_type = mat.type;
