@@ -229,7 +229,8 @@ struct SceneView {
   uint32_t small_bytes;                  // FEAT_SMALL: size of the LDS image (a multiple of 16), else 0
   const float* small_image;              // FEAT_SMALL: the LDS image in HBM (layout above)
   uint32_t small_off[SMALL_OFF_COUNT];   // byte offsets of its tables
-  uint32_t pad_;
+  uint32_t lds_insts;                    // traversal-restart kernels: instances (all of them) + the distant lights kept in LDS behind
+                                         // the stack, or 0 (they stay in global memory); set by the launcher
 };
 
 // scene feature bits -> kernel specialisation
@@ -255,7 +256,7 @@ struct RenderParams {
   uint32_t seed_state0;    // state of PCG32si::new(master seed): the seed of global frame g is the stream's g-th output
   uint32_t first_frame;    // global number of the launch's frame 0 ...
   uint32_t frame_stride;   // ... and of the step to its next one (RENE_SHARD_FRAMES deals frames round-robin; else 1)
-  uint32_t pad0_;
+  uint32_t stack_entries;  // traversal-restart kernels: the LDS stack's depth (what follows it in LDS starts at stack_entries * BLOCK words)
   uint32_t* work_counter;  // next work id
   unsigned long long* counters;  // 9 x u64
   uint32_t n_frames;

@@ -13,6 +13,7 @@ struct LaunchConfig {
   uint32_t grid = 0;         // workgroups of the persistent render launch (upper bound)
   uint32_t cus = 0;          // compute units of the device
   uint32_t wave_stack = 0;   // wavefront integrator: LDS traversal stack entries per lane (exact tree depth)
+  uint32_t n_insts = 0;      // instances of the scene (the restart kernels keep a small table of them in LDS)
 };
 
 // workgroups of the calling thread's most recent persistent render launch after fit_grid's clamp (rene_hip.cpp)

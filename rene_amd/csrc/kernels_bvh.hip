@@ -14,11 +14,30 @@ static hipError_t launch_bvh(const LaunchConfig& cfg, const SceneView& S, const 
   // a tree of a few hundred nodes is shallow and its rays stay coherent: the plain while-while loop wins there
   // (forced-BVH Cornell 17.2 vs 10.9, veach-mis 10.8 vs 6.3, zoo 5.1 vs 3.3 Grays/s); deep trees need the restart
   // scheduling (teapot-class 4.4 vs 3.5, dragon-class 4.4 vs 2.0)
-  if ((P.flags & RENE_FLAG_NO_RESTART) || S.main.n_nodes <= 512u) kernel = (count || aov) ? render_kernel<FEAT, MAXL, true, true> : render_kernel<FEAT, MAXL, false, false>;
-  else if (count) kernel = render_kernel_wf<FEAT, MAXL, true, true>;
-  else if (aov) kernel = render_kernel_wf<FEAT, MAXL, false, true>;
+  SceneView V = S;
+  V.lds_insts = 0;
+  if ((P.flags & RENE_FLAG_NO_RESTART) || S.main.n_nodes <= 512u) {
+    kernel = (count || aov) ? render_kernel<FEAT, MAXL, true, true> : render_kernel<FEAT, MAXL, false, false>;
+  } else {
+    if (count) kernel = render_kernel_wf<FEAT, MAXL, true, true>;
+    else if (aov) kernel = render_kernel_wf<FEAT, MAXL, false, true>;
+    // the restart kernels keep the instance records and the distant lights in LDS behind the stack when that still leaves
+    // four workgroups per CU (a quarter of 160 KB each): every shaded hit reads its instance, every light loop its light
+    P.stack_entries = cfg.stack_depth;
+    const size_t tables = (size_t)cfg.n_insts * sizeof(Inst) + (size_t)S.lights_len * sizeof(Light);
+    // (not for the Substrate-only instantiation: it is held at 128 registers for its fourth wave, and the LDS pointers
+    // tip it into spilling)
+    constexpr bool kTables = !((FEAT & FEAT_GENERAL_BSDF) && (FEAT & FEAT_NO_SPECULAR) && (FEAT & FEAT_NO_MICROFACET));
+    if constexpr (kTables) {
+      if (!count && aov && cfg.n_insts && lds + tables <= 40u * 1024u && !std::getenv("RENE_NO_LDS_TABLES")) {  // (the knob: A/B tests)
+        kernel = render_kernel_wf<FEAT, MAXL, false, true, true>;
+        V.lds_insts = cfg.n_insts;
+        lds += tables;
+      }
+    }
+  }
   fit_grid(kernel, lds, cfg, P, grid);
-  hipLaunchKernelGGL(kernel, grid, block, lds, st, S, P);
+  hipLaunchKernelGGL(kernel, grid, block, lds, st, V, P);
   return hipGetLastError();
 }
 

@@ -521,6 +521,7 @@ static int rene_create_impl(const rene_scene_desc* scene, const rene_opts* opts,
   c->cfg.features = ps.features;
   if (o.flags & RENE_FLAG_FORCE_BVH) c->cfg.features &= ~rene::FEAT_SMALL;
   c->cfg.stack_depth = stack;
+  c->cfg.n_insts = (uint32_t)ps.insts.size();
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, o.device));
   c->cfg.grid = (uint32_t)prop.multiProcessorCount * 8u;  // persistent launch: upper bound, clamped to the co-resident blocks at launch

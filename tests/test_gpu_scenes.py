@@ -306,3 +306,42 @@ def test_wavefront_fp16_ray_payload(oracle_mod):
     with api.Renderer(s) as r0, api.Renderer(s, flags=abi.FLAG_FP16_PAYLOAD) as r1:
         r0.render(0, 4); r1.render(0, 4)
         assert np.array_equal(r0.download(0), r1.download(0))
+
+
+def _zoo_with_a_big_mesh():
+    """material_zoo plus a 7 680-triangle displaced sphere of Metal: every material kind, deep enough a tree for the
+    traversal-restart kernels (multi-lobe instantiation)."""
+    s = scenes.material_zoo(128, 96)
+    s.add_triangle_mesh(scenes.displaced_sphere(60, 64), s.add_metal(scenes._VEACH_ETA, scenes._VEACH_K, 0.1, 0.1, remap_roughness=True),
+                        ctm=scenes.glam.from_translation((0.0, 1.6, 1.0)))
+    return s
+
+
+def _dragon_with_a_metal_ball():
+    """dragon-class (Matte, one distant light) plus a Metal sphere: the general single-lobe restart kernel."""
+    s = scenes.dragon_class(160, 90, 40, 44)
+    s.add_sphere(0.25, s.add_metal(scenes._VEACH_ETA, scenes._VEACH_K, 0.05, 0.05, remap_roughness=False),
+                 ctm=scenes.glam.from_translation((-0.4, 0.25, 0.3)))
+    return s
+
+
+@pytest.mark.parametrize("name", ["dragon", "dragon+metal", "zoo+mesh"])
+def test_instance_and_light_tables_in_lds_are_bit_identical(monkeypatch, name):
+    """The traversal-restart kernels come in two instantiations: the instance records and the distant lights read from
+    global memory, or from a copy in LDS behind the traversal stack (picked when it fits; RENE_NO_LDS_TABLES, read at every
+    launch, keeps the first).  Same records, so the same image bit for bit."""
+    scene = {"dragon": lambda: scenes.dragon_class(160, 90, 40, 44), "dragon+metal": _dragon_with_a_metal_ball,
+             "zoo+mesh": _zoo_with_a_big_mesh}[name]()
+    assert not (api.pack_info(scene).features & abi.FEAT_SMALL) and api.pack_info(scene).n_nodes_main > 512
+    images = []
+    for knob in (None, "1"):
+        if knob is None:
+            monkeypatch.delenv("RENE_NO_LDS_TABLES", raising=False)
+        else:
+            monkeypatch.setenv("RENE_NO_LDS_TABLES", knob)
+        with api.Renderer(scene) as r:
+            r.render(0, 5)
+            r.render(5, 3)
+            images.append([r.download(l) for l in range(3)])
+    for a, b in zip(*images):
+        assert np.array_equal(a, b)
