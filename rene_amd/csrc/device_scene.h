@@ -177,10 +177,11 @@ constexpr float SMALL_KIND_QUAD = 0.0f, SMALL_KIND_TRIANGLE = 1.0f, SMALL_KIND_S
 //   small_off[SMALL_OFF_EMIT]  per emitter slot, 80 B: PrimIsect (48) | EmitPdf (16) | primitive_count 0 0 0
 //   small_off[SMALL_OFF_EOBJ]  EmitObject[] (64 B each)
 //   small_off[SMALL_OFF_ETRI]  EmitTri[] (48 B each)
+//   small_off[SMALL_OFF_SPHERES]  Sphere[] (96 B each): a hit on a sphere, or the pdf of a sphere emitter, reads its matrices
 // A scene whose image would not fit is not FEAT_SMALL (it renders through the BVH kernels).
 constexpr uint32_t SMALL_LDS_MAX_BYTES = 22u * 1024u;  // six workgroups per CU keep image + frame seeds in 160 KB of LDS
 constexpr uint32_t SMALL_LDS_MAX_SEEDS = 1024u;        // a launch's frame seeds follow the image in LDS when it has at most this many frames
-enum : uint32_t { SMALL_OFF_EMIT_ITEMS = 0, SMALL_OFF_HIT, SMALL_OFF_EMIT, SMALL_OFF_EOBJ, SMALL_OFF_ETRI, SMALL_OFF_COUNT };
+enum : uint32_t { SMALL_OFF_EMIT_ITEMS = 0, SMALL_OFF_HIT, SMALL_OFF_EMIT, SMALL_OFF_EOBJ, SMALL_OFF_ETRI, SMALL_OFF_SPHERES, SMALL_OFF_COUNT };
 constexpr uint32_t SMALL_HIT_FLOATS = 52, SMALL_EMIT_FLOATS = 20;
 
 // one traversable structure

@@ -1021,6 +1021,9 @@ int pack_scene(const rene_scene_desc* d, PackedScene& out, std::string& err) {
     for (const EmitObject& e : out.emit_objects) append(reinterpret_cast<const float*>(&e), 16);
     out.small_off[SMALL_OFF_ETRI] = (uint32_t)(img.size() * 4);
     for (const EmitTri& e : out.emit_tris) append(e.q, 12);
+    out.small_off[SMALL_OFF_SPHERES] = (uint32_t)(img.size() * 4);
+    static_assert(sizeof(Sphere) == 96, "LDS image record sizes");
+    for (const Sphere& sp : out.spheres) append(reinterpret_cast<const float*>(&sp), 24);
     if (img.size() * 4 <= SMALL_LDS_MAX_BYTES) out.features |= FEAT_SMALL;
     else img.clear();  // too many slots for the LDS-resident tables: the BVH kernels render it
   }
