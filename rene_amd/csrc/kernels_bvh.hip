@@ -25,15 +25,10 @@ static hipError_t launch_bvh(const LaunchConfig& cfg, const SceneView& S, const 
     // four workgroups per CU (a quarter of 160 KB each): every shaded hit reads its instance, every light loop its light
     P.stack_entries = cfg.stack_depth;
     const size_t tables = (size_t)cfg.n_insts * sizeof(Inst) + (size_t)S.lights_len * sizeof(Light);
-    // (not for the Substrate-only instantiation: it is held at 128 registers for its fourth wave, and the LDS pointers
-    // tip it into spilling)
-    constexpr bool kTables = !((FEAT & FEAT_GENERAL_BSDF) && (FEAT & FEAT_NO_SPECULAR) && (FEAT & FEAT_NO_MICROFACET));
-    if constexpr (kTables) {
-      if (!count && aov && cfg.n_insts && lds + tables <= 40u * 1024u && !std::getenv("RENE_NO_LDS_TABLES")) {  // (the knob: A/B tests)
-        kernel = render_kernel_wf<FEAT, MAXL, false, true, true>;
-        V.lds_insts = cfg.n_insts;
-        lds += tables;
-      }
+    if (!count && aov && cfg.n_insts && lds + tables <= 40u * 1024u && !std::getenv("RENE_NO_LDS_TABLES")) {  // (the knob: A/B tests)
+      kernel = render_kernel_wf<FEAT, MAXL, false, true, true>;
+      V.lds_insts = cfg.n_insts;
+      lds += tables;
     }
   }
   fit_grid(kernel, lds, cfg, P, grid);

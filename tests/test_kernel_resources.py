@@ -52,7 +52,7 @@ def test_production_variants_keep_their_occupancy(hip_lib):
     for tables in ("Lb0E", "Lb1E"):
         assert one("render_kernel_wfILj8ELi1ELb0ELb1E" + tables)["occupancy"] >= 4
         assert one("render_kernel_wfILj31ELi1ELb0ELb1E" + tables)["occupancy"] >= 3 and one("render_kernel_wfILj31ELi1ELb0ELb1E" + tables)["scratch"] == 0
-    assert one("render_kernel_wfILj1302ELi1ELb0ELb1ELb0E")["occupancy"] >= 4 and one("render_kernel_wfILj1302ELi1ELb0ELb1ELb0E")["scratch"] == 0  # Substrate-only
+        assert one("render_kernel_wfILj1302ELi1ELb0ELb1E" + tables)["occupancy"] >= 4 and one("render_kernel_wfILj1302ELi1ELb0ELb1E" + tables)["scratch"] == 0  # Substrate-only
     # multi-lobe kernels: two waves (they were at one, with 376 bytes of scratch per lane)
     assert one("render_kernelILj127ELi5ELb0ELb1")["occupancy"] >= 2
     # traversal passes of the wavefront integrator are register-light by construction
