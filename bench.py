@@ -36,6 +36,8 @@ The JSON line also carries
   configs      -- N = 1 only: the other BASELINE configurations that fit one GPU, one full job each at its own
                   resolution and sample count (C3 veach-mis 1024x1024 @ 4096 spp, C4 dragon-class 1920x1080 @ 1024 spp,
                   C5 teapot-class 1920x1080 @ 8192 spp), each with rays, Mrays/s, ms/frame and the same two fractions.
+                  Each runs in a process of its own, before this one touches the GPU, under --config-timeout seconds:
+                  one that fails or stalls is reported as an error entry and does not take the headline line with it.
   cpu_baseline -- the CPU oracle (a port of rene's integrator; the reference itself has no CPU
                   path and cannot be built here) timed on this host's cores on a bounded sample.
 """
@@ -112,6 +114,61 @@ def algorithmic_bytes_per_ray(packed, api, abi, device, frames=4, **shard):
     return abi.algorithmic_bytes(cst) / max(1, cst.rays)
 
 
+def run_config(name: str, device: int = 0):
+    """One full job of one of the additional configurations (C3-C5) on `device`: its figures for the `configs` object."""
+    import numpy as np
+    import torch
+    from rene_amd import abi, api
+    lab, mk, spp, fpl = configurations()[name]
+    overlap = abi.FLAG_OVERLAP if os.environ.get("RENE_BENCH_OVERLAP", "1") != "0" else 0
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    sc = mk()
+    pk = sc if hasattr(sc, "byref") else sc.to_desc()
+    bpr = algorithmic_bytes_per_ray(pk, api, abi, device, frames=2)
+    with api.Renderer(pk, device=device, flags=overlap) as rr:
+        rr.tune(fpl)
+        rr.render(0, fpl)
+        rr.sync()
+        rr.reset()
+        t1 = time.perf_counter()
+        for f0 in range(0, spp, fpl):
+            rr.render(f0, min(fpl, spp - f0))
+        rr.sync()
+        dt = time.perf_counter() - t1
+        s2 = rr.stats()
+        im = rr.download(0)
+    assert bool(np.isfinite(im).all()) and float(im.mean()) > 0.0, f"{name}: image empty or non-finite"
+    rl2 = rooflines(name, s2.rays / dt, cus, bpr)
+    return {"workload": lab, "width": pk.xres, "height": pk.yres, "spp": spp, "frames_per_launch": fpl,
+            "triangles": api.pack_info(pk).n_triangles, "rays": s2.rays, "rays_per_path": s2.rays / max(1, s2.paths),
+            "value": s2.rays / dt / 1e6, "unit": "Mrays/s", "seconds": dt, "ms_per_frame": dt / spp * 1e3,
+            "launch_ms": s2.kernel_ms / max(1, s2.launches), "launch_period_ms": dt * 1e3 / max(1, s2.launches),
+            "kernel": (pmc_per_ray(name) or {}).get("kernel"),
+            "valu": rl2["valu"], "hbm": rl2["hbm"]}
+
+
+def configs_in_children(head: str, timeout_s: float):
+    """Every additional configuration in a process of its own, one after the other, BEFORE this process touches the GPU
+    (a process that has initialised HIP must not be the one that spawns).  A configuration that fails or does not finish in
+    time is reported as such instead of taking the headline line down with it."""
+    import subprocess
+    out = {}
+    for name in configurations():
+        if name == head:
+            continue
+        cmd = [sys.executable, os.path.abspath(__file__), "--config-child", name]
+        try:
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s, text=True)
+            lines = [l for l in p.stdout.splitlines() if l.startswith('{"config"')]
+            if p.returncode == 0 and lines:
+                out[name] = json.loads(lines[-1])["config"]
+            else:
+                out[name] = {"error": f"exit code {p.returncode}", "stderr_tail": p.stderr[-400:]}
+        except subprocess.TimeoutExpired:
+            out[name] = {"error": f"did not finish within {timeout_s:.0f} s (killed)"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -121,7 +178,18 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the additional configurations (C3-C5)")
     ap.add_argument("--cpu-spp", type=int, default=128, help="frames of the CPU-oracle baseline sample (~10 s on 16 threads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config-child", default=None, help=argparse.SUPPRESS)  # one additional configuration in this process (see configs_in_children)
+    ap.add_argument("--config-timeout", type=float, default=300.0, help="seconds an additional configuration may take before it is given up")
     args = ap.parse_args()
+    if args.config_child:
+        import torch
+        torch.cuda.set_device(0)
+        print(json.dumps({"config": run_config(args.config_child, 0)}), flush=True)
+        return
+    # the additional configurations first, each in its own process (only the one-GPU run reports them)
+    child_configs = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and max(1, args.gpus) == 1 and not args.no_configs and not args.only:
+        child_configs = configs_in_children("cornell", args.config_timeout)
 
     import numpy as np
     import torch
@@ -305,38 +373,9 @@ def main():
                                  "(HIP events; what rocprofv3 reports per dispatch) but one completes every `launch_period_ms`; "
                                  "`hbm.frac` is measured HBM traffic (PMC) against 8 TB/s"},
         }
-        # ---- the other configurations, one full job each (N = 1 only) ----
-        if n_gpus == 1 and not args.no_configs and not args.only:
-            out["configs"] = {}
-            r.close()
-            del fb
-            for name, (lab, mk, spp, fpl) in cfgs.items():
-                if name == head:
-                    continue
-                sc = mk()
-                pk = sc if hasattr(sc, "byref") else sc.to_desc()
-                bpr = algorithmic_bytes_per_ray(pk, api, abi, local, frames=2)
-                with api.Renderer(pk, device=local, flags=overlap) as rr:
-                    rr.tune(fpl)
-                    rr.render(0, fpl)
-                    rr.sync()
-                    rr.reset()
-                    t1 = time.perf_counter()
-                    for f0 in range(0, spp, fpl):
-                        rr.render(f0, min(fpl, spp - f0))
-                    rr.sync()
-                    dt = time.perf_counter() - t1
-                    s2 = rr.stats()
-                    im = rr.download(0)
-                assert bool(np.isfinite(im).all()) and float(im.mean()) > 0.0, f"{name}: image empty or non-finite"
-                rl2 = rooflines(name, s2.rays / dt, cus, bpr)
-                out["configs"][name] = {
-                    "workload": lab, "width": pk.xres, "height": pk.yres, "spp": spp, "frames_per_launch": fpl,
-                    "triangles": api.pack_info(pk).n_triangles, "rays": s2.rays, "rays_per_path": s2.rays / max(1, s2.paths),
-                    "value": s2.rays / dt / 1e6, "unit": "Mrays/s", "seconds": dt, "ms_per_frame": dt / spp * 1e3,
-                    "launch_ms": s2.kernel_ms / max(1, s2.launches), "launch_period_ms": dt * 1e3 / max(1, s2.launches),
-                    "kernel": (pmc_per_ray(name) or {}).get("kernel"),
-                    "valu": rl2["valu"], "hbm": rl2["hbm"]}
+        # ---- the other configurations, one full job each (N = 1 only; measured in child processes before this one started) ----
+        if child_configs is not None:
+            out["configs"] = child_configs
         if n_gpus == 1 and not args.no_cpu_baseline:
             from oracle import oracle  # CPU checker used here only as the reported baseline
             o = oracle.Oracle(packed)

@@ -203,6 +203,12 @@ struct Uniforms {
   float proj_inv[16];
   float bg_matrix[16];
   float bg_color[4];
+  // the background texture resolved at upload (main_miss would otherwise walk texture record -> image record -> texels):
+  // bg_kind 0 = go through the texture tables, 1 = a Solid texture (bg_solid), 2 = an ImageMap (bg_image_*)
+  uint32_t bg_kind, bg_image_width, bg_image_height, bg_pad;
+  unsigned long long bg_image_offset;  // float offset into the image pool
+  unsigned long long bg_pad2;
+  float bg_solid[4];
 };
 
 // everything a kernel needs, passed by value (lives in SGPRs / kernarg)

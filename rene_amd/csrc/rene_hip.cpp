@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -137,6 +138,27 @@ Rccl* rccl() {
   } while (0)
 }  // namespace
 
+
+// Host-side waits poll (hipEventQuery / hipStreamQuery read the completion signal) instead of blocking in the runtime: a
+// blocked wait depends on a wake-up from the driver, and on this pool a job of many overlapped launches was seen to sit in
+// one for minutes now and then; polling costs one host thread a few microseconds of latency.
+static hipError_t wait_event(hipEvent_t ev) {
+  for (uint64_t spins = 0;; ++spins) {
+    const hipError_t e = hipEventQuery(ev);
+    if (e != hipErrorNotReady) return e;
+    if (spins < 2000) std::this_thread::yield();
+    else std::this_thread::sleep_for(std::chrono::microseconds(20));
+  }
+}
+static hipError_t wait_stream(hipStream_t st) {
+  for (uint64_t spins = 0;; ++spins) {
+    const hipError_t e = hipStreamQuery(st);
+    if (e != hipErrorNotReady) return e;
+    if (spins < 2000) std::this_thread::yield();
+    else std::this_thread::sleep_for(std::chrono::microseconds(20));
+  }
+}
+
 struct rene_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -239,7 +261,7 @@ struct rene_ctx {
     const Pending* same = nullptr;
     for (auto it = pending.rbegin(); it != pending.rend(); ++it)
       if (it->second_stream == second_stream) { same = &*it; break; }
-    if (same) HIP_TRY(hipEventSynchronize(same->stop));
+    if (same) HIP_TRY(wait_event(same->stop));
     if (pending.empty() || pending.back().second_stream == second_stream) return RENE_OK;
     const Pending& prev = pending.back();
     const auto t0 = std::chrono::steady_clock::now();
@@ -268,7 +290,7 @@ struct rene_ctx {
         if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
           if (std::getenv("RENE_DEBUG")) std::fprintf(stderr, "[rene] admit: launch %u not resident after 200 ms, waiting for it\n", prev.epoch);
           // a device shared with other work may keep part of that launch out for long: then simply let it finish
-          HIP_TRY(hipEventSynchronize(prev.stop));
+          HIP_TRY(wait_event(prev.stop));
           return RENE_OK;
         }
       }
@@ -297,8 +319,8 @@ struct rene_ctx {
       int rc_ = flush_exchange();
       if (rc_ != RENE_OK) return rc_;
     }
-    HIP_TRY(hipStreamSynchronize(stream));
-    if (stream2) HIP_TRY(hipStreamSynchronize(stream2));
+    HIP_TRY(wait_stream(stream));
+    if (stream2) HIP_TRY(wait_stream(stream2));
     const bool had_launches = !pending.empty();
     if (counters_used && d_wave_times) {  // RENE_DEBUG: per launch, when its waves started and ended (ms since the first start)
       std::vector<unsigned long long> t((size_t)counters_used * 8192 * 2);
@@ -500,10 +522,24 @@ static int rene_create_impl(const rene_scene_desc* scene, const rene_opts* opts,
   for (uint32_t k = 0; k < rene::SMALL_OFF_COUNT; ++k) v.small_off[k] = ps.small_off[k];
   {
     std::vector<rene::Uniforms> u(1);
+    std::memset(&u[0], 0, sizeof(u[0]));
     std::memcpy(u[0].c2w, ps.uniform.camera_to_world, 64);
     std::memcpy(u[0].proj_inv, ps.uniform.projection_inv, 64);
     std::memcpy(u[0].bg_matrix, ps.uniform.background_matrix, 64);
     std::memcpy(u[0].bg_color, ps.uniform.background_color, 16);
+    u[0].bg_kind = 0;
+    if (ps.uniform.background_texture < ps.textures.size() && !std::getenv("RENE_NO_RESOLVE")) {
+      const rene::Texture& t = ps.textures[ps.uniform.background_texture];
+      if (t.type == RENE_TEXTURE_SOLID) {
+        u[0].bg_kind = 1;
+        std::memcpy(u[0].bg_solid, t.v0, 12);
+      } else if (t.type == RENE_TEXTURE_IMAGEMAP && t.u0[0] < ps.images.size()) {
+        u[0].bg_kind = 2;
+        u[0].bg_image_offset = ps.images[t.u0[0]].offset;
+        u[0].bg_image_width = ps.images[t.u0[0]].width;
+        u[0].bg_image_height = ps.images[t.u0[0]].height;
+      }
+    }
     int rc_ = c->upload(u, &v.uni);
     if (rc_ != RENE_OK) return rc_;
   }
