@@ -143,9 +143,18 @@ Rccl* rccl() {
 // blocked wait depends on a wake-up from the driver, and on this pool a job of many overlapped launches was seen to sit in
 // one for minutes now and then; polling costs one host thread a few microseconds of latency.
 static hipError_t wait_event(hipEvent_t ev) {
+  const auto t0 = std::chrono::steady_clock::now();
+  int told = 0;
   for (uint64_t spins = 0;; ++spins) {
     const hipError_t e = hipEventQuery(ev);
     if (e != hipErrorNotReady) return e;
+    if ((spins & 0xfffu) == 0xfffu && std::getenv("RENE_DEBUG")) {
+      const double s_ = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (s_ > 10.0 * (told + 1)) {
+        ++told;
+        std::fprintf(stderr, "[rene] still waiting for a launch to complete after %.0f s (its completion signal has not fired)\n", s_);
+      }
+    }
     if (spins < 2000) std::this_thread::yield();
     else std::this_thread::sleep_for(std::chrono::microseconds(20));
   }
