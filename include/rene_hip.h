@@ -233,7 +233,7 @@ typedef struct rene_stats {
   uint64_t node_visits;   /* only with RENE_FLAG_COUNTERS */
   uint64_t prim_tests;    /* only with RENE_FLAG_COUNTERS */
   uint64_t frames;        /* frames rendered so far (per context) */
-  uint64_t launches;      /* kernel launches so far */
+  uint64_t launches;      /* kernel launches so far (a launch that had to be replayed after dropped work items counts again) */
   double kernel_ms;       /* sum of HIP-event durations of those launches */
   double last_launch_ms;
 } rene_stats;

@@ -7,6 +7,9 @@
 
 namespace rene {
 
+constexpr uint32_t RENE_FLAG_INTERNAL_TEST_DROP = 1u << 29;  // RenderParams.flags, set by rene_render under RENE_TEST_DROP=<launch>: some items of that
+                                                             // launch are dropped as if their hand-off had timed out (tests of the replay)
+
 struct LaunchConfig {
   uint32_t features = 0;     // FEAT_* of the scene
   uint32_t stack_depth = 16; // LDS traversal stack entries per lane

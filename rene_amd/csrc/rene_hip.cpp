@@ -210,7 +210,11 @@ struct rene_ctx {
     hipEvent_t start, stop;
     bool second_stream;
     uint32_t epoch, waves;
+    bool replayable = false;    // a persistent render launch: what it was launched with, should it have to be launched again
+    rene::RenderParams P{};
+    rene::LaunchConfig cfg{};
   };
+  uint64_t replays = 0;         // launches launched again by drain() (RENE_DEBUG prints them)
   bool overlap() const { return stream2 != nullptr; }
   // order everything launched on stream2 before whatever is enqueued on `stream` next (callers that handed in their
   // own stream consume the framebuffer there)
@@ -356,6 +360,35 @@ struct rene_ctx {
       HIP_TRY(hipMemset(d_work_counters, 0, kCounters * sizeof(uint32_t)));
       counters_used = 0;
     }
+    // Items whose hand-off did not come were DROPPED by their lanes (device_code.inc: the waves that render the awaited
+    // item can be parked by the driver behind this launch's own -- a queue eviction restores the queues in its own order --
+    // and from then on every waiter of this and of the following launches drops too).  Nothing wrong has been added to the
+    // image: the launches since the last sync are launched again, one at a time on an idle device, in their order and with
+    // their own parameters; an item that was committed the first time finds its pixel's version ahead of it and is skipped.
+    if (had_launches && d_counters && !handoff_failed) {
+      for (int attempt = 0; attempt < 3; ++attempt) {
+        unsigned long long dropped = 0;
+        HIP_TRY(hipMemcpy(&dropped, d_counters + 8, sizeof(dropped), hipMemcpyDeviceToHost));
+        if (!dropped) break;
+        bool all = true;
+        for (const Pending& p : pending) all = all && p.replayable;
+        if (!all) break;  // (the wavefront integrator's launches are not of this kind)
+        if (std::getenv("RENE_DEBUG")) std::fprintf(stderr, "[rene] %llu work items were dropped: launching the last %zu launch(es) again, serially (attempt %d)\n", dropped, pending.size(), attempt + 1);
+        HIP_TRY(hipMemset(d_counters + 8, 0, 4 * sizeof(unsigned long long)));
+        for (Pending& p : pending) {
+          HIP_TRY(hipMemset(d_work_counters, 0, kCounters * sizeof(uint32_t)));
+          rene::RenderParams P = p.P;
+          P.flags &= ~rene::RENE_FLAG_INTERNAL_TEST_DROP;
+          P.resident = nullptr;
+          rene::g_launched_blocks = p.cfg.grid;
+          hipError_t e = rene::launch_render(p.cfg, view, P, stream);
+          if (e != hipSuccess) return fail(RENE_ERR_DEVICE, std::string("render launch (replay): ") + hipGetErrorString(e));
+          HIP_TRY(wait_stream(stream));
+          ++replays;
+        }
+        HIP_TRY(hipMemset(d_work_counters, 0, kCounters * sizeof(uint32_t)));
+      }
+    }
     while (!pending.empty()) {
       Pending& p = pending.front();
       float ms = 0.0f;
@@ -367,8 +400,8 @@ struct rene_ctx {
       hipEventDestroy(p.stop);
       pending.pop_front();
     }
-    // a work-item hand-off that gave up (device_code.inc, `give_up`) took the sums as they were: the image is wrong, and
-    // every call that hands results to the caller (rene_sync, rene_download, rene_get_stats, rene_reduce) must say so
+    // items still dropped after three replays on an idle device: something else is wrong, and every call that hands
+    // results to the caller (rene_sync, rene_download, rene_get_stats, rene_reduce) must say so
     if (had_launches && d_counters && !handoff_failed) {
       unsigned long long t[4] = {0, 0, 0, 0};
       HIP_TRY(hipMemcpy(t, d_counters + 8, sizeof(t), hipMemcpyDeviceToHost));
@@ -377,7 +410,7 @@ struct rene_ctx {
         handoff_detail = " [" + std::to_string(t[0]) + " lanes gave up; the first: work id " + std::to_string(t[1]) + " of " + std::to_string(n_work) + " slots per level, in launch " +
                          std::to_string(t[2] >> 32) + ", wanted version " + std::to_string(t[3]) + ", saw " + std::to_string(t[2] & 0xffffffffu) + "]";
     }
-    if (handoff_failed) return fail(RENE_ERR_DEVICE, "a work-item hand-off timed out inside the render kernel (results invalid; rene_reset clears the condition)" + handoff_detail);
+    if (handoff_failed) return fail(RENE_ERR_DEVICE, "work items were dropped inside the render kernel and replaying their launches did not complete them (results invalid; rene_reset clears the condition)" + handoff_detail);
     return RENE_OK;
   }
 };
@@ -761,6 +794,8 @@ static int rene_render_impl(rene_ctx* c, uint32_t first_frame, uint32_t n_frames
   // counter the item a lane waits for is always in the hands of a resident lane.  (The static first batch saved
   // 0.05 ms per launch.)
   P.flags |= RENE_FLAG_DYNAMIC_FIRST;
+  if (const char* e = std::getenv("RENE_TEST_DROP"))  // fault injection (tests): the context's launch number e drops some of its items
+    if ((uint32_t)std::atoi(e) == c->epoch + 1u) P.flags |= rene::RENE_FLAG_INTERNAL_TEST_DROP;
   // every pixel's frames in `levels` work items of `step` frames (device_code.inc, render_kernel)
   uint32_t levels = (c->cfg.features & rene::FEAT_SMALL) ? 4u : 8u;
   if (c->item_frames == rene_ctx::kWholeLaunch) levels = 1;
@@ -832,6 +867,9 @@ static int rene_render_impl(rene_ctx* c, uint32_t first_frame, uint32_t n_frames
   hipEventRecord(pend.stop, stream);
   pend.second_stream = second_stream;
   pend.epoch = P.epoch;
+  pend.replayable = true;
+  pend.P = P;
+  pend.cfg = cfg;
   c->counters_used++;
   pend.waves = std::min(rene::g_launched_blocks * (uint32_t)(rene::render_block_size() / 64), c->resident_words);
   c->pending.push_back(pend);
@@ -968,7 +1006,7 @@ int rene_get_stats(rene_ctx* c, rene_stats* out) {
   out->node_visits = h[6];
   out->prim_tests = h[7];
   out->frames = c->frames;
-  out->launches = c->launches;
+  out->launches = c->launches + c->replays;  // launches that had to be launched again (drain) count twice
   out->kernel_ms = c->kernel_ms;
   out->last_launch_ms = c->last_ms;
   return RENE_OK;

@@ -306,3 +306,31 @@ def test_cornell_512_at_64_spp_overlapped_and_tuned_against_the_oracle(oracle_mo
         assert abs(float(g.sum() / c.sum()) - 1) < 2e-4
         aov_check(r.download(1), o.download(1), atol=2e-5 * 64)
         aov_check(r.download(2), o.download(2), atol=1e-6 * 64)
+
+
+@pytest.mark.parametrize("name", ["cornell", "dragon", "teapot"])
+def test_dropped_work_items_are_replayed_bit_identically(monkeypatch, name):
+    """A launch is restartable: an item whose hand-off does not come is dropped (not rendered on top of sums that are not its
+    own), every waiter after it drops too, and the next sync launches the launches since the last sync again, alone and in
+    order; what was committed the first time is skipped.  RENE_TEST_DROP=<n> makes the context's n-th launch drop one item
+    in 97 as if it had timed out -- with launches overlapped, in the middle of a job.  The image and the ray counts must
+    equal an undisturbed render's, on both kernel families."""
+    s = {"cornell": lambda: scenes.cornell_box(160, 128), "dragon": lambda: scenes.dragon_class(160, 90, 40, 44),
+         "teapot": lambda: scenes.teapot_class(128, 72, 20, 22)}[name]()
+    def job(r):
+        for f0 in range(0, 24, 6):
+            r.render(f0, 6)
+        r.sync()
+        return [r.download(l) for l in range(3)], r.stats().as_dict()
+    monkeypatch.delenv("RENE_TEST_DROP", raising=False)
+    with api.Renderer(s, flags=abi.FLAG_OVERLAP) as r:
+        want, sw = job(r)
+    for launch in (1, 2, 4):
+        monkeypatch.setenv("RENE_TEST_DROP", str(launch))
+        with api.Renderer(s, flags=abi.FLAG_OVERLAP) as r:
+            got, sg = job(r)
+        for a, b in zip(want, got):
+            assert np.array_equal(a, b), (name, launch)
+        for k in ("rays_closest", "rays_shadow", "rays_emitter", "hits", "adds", "paths"):
+            assert sg[k] == sw[k], (name, launch, k, sg[k], sw[k])
+        assert sg["launches"] > sw["launches"], "the injected drop must have caused a replay"
