@@ -27,8 +27,8 @@ def scene_table():
     return {
         "cornell": (lambda: scenes.cornell_box(1024, 1024), 256, 0),
         "veach-mis": (lambda: scenes.veach_mis(1024, 1024), 256, 0),
-        "dragon-class": (lambda: scenes.dragon_class(1920, 1080), 64, 0),
-        "teapot-class": (lambda: scenes.teapot_class(1920, 1080), 128, 0),
+        "dragon-class": (lambda: scenes.dragon_class(1920, 1080), 256, 0),
+        "teapot-class": (lambda: scenes.teapot_class(1920, 1080), 512, 0),
         "zoo": (lambda: scenes.material_zoo(1024, 768), 32, 0),
         "fog": (lambda: scenes.cornell_fog(1024, 1024), 16, 0),
         "media-zoo": (lambda: scenes.media_zoo(1024, 768), 16, 0),

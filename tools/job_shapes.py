@@ -18,7 +18,10 @@ def main():
         lab, mk, spp, fpl = cfgs[nm]
         sc = mk()
         pk = sc if hasattr(sc, "byref") else sc.to_desc()
-        for cut, flags in ((fpl, abi.FLAG_OVERLAP), (fpl, 0), (spp, 0), (spp // 2, abi.FLAG_OVERLAP), (spp // 2, 0)):
+        cuts = [(fpl, abi.FLAG_OVERLAP), (fpl, 0), (spp, 0), (spp // 2, abi.FLAG_OVERLAP), (spp // 2, 0)]
+        if os.environ.get("SHAPES"):  # e.g. SHAPES=64,128,256,512: overlapped launches of these sizes only
+            cuts = [(int(x), abi.FLAG_OVERLAP) for x in os.environ["SHAPES"].split(",")]
+        for cut, flags in cuts:
             cut = max(1, cut)
             with api.Renderer(pk, flags=flags) as r:
                 r.tune(cut)
