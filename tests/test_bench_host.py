@@ -1,0 +1,47 @@
+"""CPU: the host logic of bench.py that needs no GPU -- its configurations, the roofline arithmetic against the committed
+per-ray records, and the child-process harness of the additional configurations (a child that fails or stalls must become an
+error entry, not a missing headline line)."""
+import json
+import os
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_configurations_and_records():
+    cfgs = bench.configurations()
+    assert list(cfgs)[0] == "cornell" and set(cfgs) == {"cornell", "veach-mis", "dragon-class", "teapot-class"}
+    for name, (label, make, spp, fpl) in cfgs.items():
+        assert spp % fpl == 0 and callable(make) and str(spp) in label
+        rec = bench.pmc_per_ray(name)
+        assert rec and rec["valu_wave_insts_per_ray"] > 0 and os.path.exists(os.path.join(ROOT, rec["source"])), name
+
+
+def test_roofline_fractions_are_fractions():
+    for name in bench.configurations():
+        rl = bench.rooflines(name, 1.0e10 if name != "cornell" else 1.2e11, 256, 500.0)
+        assert 0.0 < rl["valu"]["frac"] <= 1.0 and rl["valu"]["peak"] == pytest.approx(78.6432)
+        assert 0.0 <= rl["hbm"]["frac"] <= 1.0 and rl["hbm"]["peak"] == 8000.0
+
+
+def test_a_failing_or_stalling_configuration_becomes_an_error_entry(monkeypatch, tmp_path):
+    """configs_in_children runs `bench.py --config-child NAME` per configuration; here the 'bench.py' it starts is a stand-in
+    that succeeds for one name, fails for another and sleeps past the timeout for the third."""
+    fake = tmp_path / "fake_bench.py"
+    fake.write_text(
+        "import json, sys, time\n"
+        "name = sys.argv[sys.argv.index('--config-child') + 1]\n"
+        "if name == 'veach-mis': print(json.dumps({'config': {'value': 1.0}}))\n"
+        "elif name == 'dragon-class': sys.stderr.write('boom'); sys.exit(3)\n"
+        "else: time.sleep(30)\n")
+    monkeypatch.setattr(bench, "__file__", str(fake))
+    out = bench.configs_in_children("cornell", timeout_s=2.0)
+    assert out["veach-mis"] == {"value": 1.0}
+    assert "exit code 3" in out["dragon-class"]["error"] and "boom" in out["dragon-class"]["stderr_tail"]
+    assert "did not finish" in out["teapot-class"]["error"]
+    json.dumps(out)
