@@ -260,7 +260,7 @@ typedef struct rene_pack_info {
   uint32_t n_nodes_emit, n_slots_emit, depth_emit;
   uint32_t features;         /* kernel specialisation bits: 1 spheres, 2 general BSDFs, 4 textures, 8 distant lights, 16 background,
                                 32 multi-lobe materials, 64 wave-coherent item loop (no BVH), 128 volpath; for single-lobe general
-                                scenes also what is absent: 256 no Glass / Mirror, 512 no Substrate, 1024 no Metal */
+                                scenes also what is absent: 256 no Glass / Mirror, 512 no Substrate, 1024 no Metal; 2048 no emit objects */
   uint32_t emit_object_len;  /* rene/src/main.rs:3279 */
   uint32_t lights_len;       /* rene/src/scene.rs:166 */
   uint64_t device_bytes;     /* HBM the scene tables will occupy (framebuffer excluded) */

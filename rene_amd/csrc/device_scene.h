@@ -256,6 +256,8 @@ enum : uint32_t {
   FEAT_NO_BLEND = 1u << 9,       // no Substrate (FresnelBlend lobe)
   FEAT_NO_MICROFACET = 1u << 10, // no Metal (MicrofacetReflection lobe)
   FEAT_ABSENT_MASK = FEAT_NO_SPECULAR | FEAT_NO_BLEND | FEAT_NO_MICROFACET,
+  FEAT_NO_EMITTERS = 1u << 11,   // no emit objects (area lights): the emitter mixture of lib.rs:274-324 never runs (the traversal-restart
+                                 // kernels of the two large bench scenes are instantiated without it)
 };
 
 struct RenderParams {

@@ -17,7 +17,8 @@ static hipError_t launch_bvh(const LaunchConfig& cfg, const SceneView& S, const 
   SceneView V = S;
   V.lds_insts = 0;
   if ((P.flags & RENE_FLAG_NO_RESTART) || S.main.n_nodes <= 512u) {
-    kernel = (count || aov) ? render_kernel<FEAT, MAXL, true, true> : render_kernel<FEAT, MAXL, false, false>;
+    constexpr uint32_t F0 = FEAT & ~FEAT_NO_EMITTERS;  // (the while-while loop has no instantiation of its own for that bit)
+    kernel = (count || aov) ? render_kernel<F0, MAXL, true, true> : render_kernel<F0, MAXL, false, false>;
   } else {
     if (count) kernel = render_kernel_wf<FEAT, MAXL, true, true>;
     else if (aov) kernel = render_kernel_wf<FEAT, MAXL, false, true>;
@@ -45,11 +46,15 @@ hipError_t launch_render_bvh(const LaunchConfig& cfg, const SceneView& S, const 
   constexpr uint32_t GEN1 = ALL & ~FEAT_MULTI_LOBE;
   const uint32_t f = cfg.features;
   if (!(f & (FEAT_SPHERES | FEAT_GENERAL_BSDF | FEAT_TEXTURES | FEAT_BACKGROUND | FEAT_MULTI_LOBE)))
-    return launch_bvh<FEAT_LIGHTS, 1>(cfg, S, P, st);
+    return (f & FEAT_NO_EMITTERS) ? launch_bvh<FEAT_LIGHTS | FEAT_NO_EMITTERS, 1>(cfg, S, P, st)  // dragon-class: distant lights only
+                                  : launch_bvh<FEAT_LIGHTS, 1>(cfg, S, P, st);
   // general single-lobe scenes without spheres and distant lights (teapot-class: Substrate + textures + environment map)
   if (!(f & (FEAT_MULTI_LOBE | FEAT_SPHERES | FEAT_LIGHTS))) {
-    if ((f & FEAT_NO_SPECULAR) && (f & FEAT_NO_MICROFACET))  // ... and Substrate as the only general material
-      return launch_bvh<FEAT_GENERAL_BSDF | FEAT_TEXTURES | FEAT_BACKGROUND | FEAT_NO_SPECULAR | FEAT_NO_MICROFACET, 1>(cfg, S, P, st);
+    if ((f & FEAT_NO_SPECULAR) && (f & FEAT_NO_MICROFACET)) {  // ... and Substrate as the only general material
+      constexpr uint32_t SUB = FEAT_GENERAL_BSDF | FEAT_TEXTURES | FEAT_BACKGROUND | FEAT_NO_SPECULAR | FEAT_NO_MICROFACET;
+      return (f & FEAT_NO_EMITTERS) ? launch_bvh<SUB | FEAT_NO_EMITTERS, 1>(cfg, S, P, st)  // the teapot scenes: an environment light only
+                                    : launch_bvh<SUB, 1>(cfg, S, P, st);
+    }
     return launch_bvh<FEAT_GENERAL_BSDF | FEAT_TEXTURES | FEAT_BACKGROUND, 1>(cfg, S, P, st);
   }
   if (!(f & FEAT_MULTI_LOBE)) return launch_bvh<GEN1, 1>(cfg, S, P, st);

@@ -983,6 +983,7 @@ int pack_scene(const rene_scene_desc* d, PackedScene& out, std::string& err) {
     out.insts.push_back(inst);
   }
   if (prims.size() > LEAF_FIRST_MASK) { err = "too many primitives for the 26-bit leaf index"; return RENE_ERR_UNSUPPORTED; }
+  if (out.emit_objects.empty()) out.features |= FEAT_NO_EMITTERS;
 
   std::vector<uint32_t> order;
   uint32_t max_leaf = 2;  // measured with the BVH4 (MI355X, Grays/s, dragon- / teapot-class): 1: 4.42 / 4.23, 2: 4.82 / 4.63, 3: 4.56 / 4.47, 4: 4.35 / 4.32, 8: 3.66 / 3.86

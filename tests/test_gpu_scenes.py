@@ -110,7 +110,7 @@ def test_teapot_class_substrate_checkerboard_envmap(oracle_mod):
     distant light): the general single-lobe traversal-restart kernel with textures and a background."""
     s = scenes.teapot_class(160, 90, n_lat=40, n_lon=42)
     info = api.pack_info(s)
-    assert info.n_triangles == 2 * 40 * 42 + 2 and (info.features & 0xff) == (2 | 4 | 16) and (info.features >> 8) == (1 | 4)  # general, textures, background; no specular, no microfacet lobes
+    assert info.n_triangles == 2 * 40 * 42 + 2 and (info.features & 0xff) == (2 | 4 | 16) and (info.features >> 8) == (1 | 4 | 8)  # general, textures, background; no specular, no microfacet lobes, no emit objects
     sg, so = _compare(s, 16, oracle_mod, frac=5e-3, relmse=1e-3, ctol=2e-3)
     assert sg["rays_emitter"] == 0 and sg["rays_shadow"] == 0
     _compare(s, 16, oracle_mod, frac=5e-3, relmse=1e-3, ctol=2e-3, flags=abi.FLAG_NO_RESTART)

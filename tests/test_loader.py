@@ -368,7 +368,7 @@ def test_teapot_scene_loads_from_the_fixture(hip_lib, oracle_mod):
     info = api.pack_info(s)
     assert info.n_triangles == faces + 2 == 126050 and info.n_instances == 3
     # Substrate (general, no specular / microfacet lobes) + checkerboard + environment map: the teapot-class kernel
-    assert (info.features & 0xff) == (2 | 4 | 16) and (info.features >> 8) == (1 | 4)
+    assert (info.features & 0xff) == (2 | 4 | 16) and (info.features >> 8) == (1 | 4 | 8)
     assert info.emit_object_len == 0 and info.lights_len == 0 and info.depth_main <= 96
     t = s.tables()
     assert t["n_images"] == 1 and t["integrator"] == abi.INTEGRATOR_PATH
