@@ -327,6 +327,15 @@ struct rene_ctx {
     return RENE_OK;
   }
 
+  // Zeroes device memory and WAITS for it.  (hipMemset on the null stream returns before the fill has run -- it is a kernel, and
+  // behind a persistent launch on another queue it gets a slot only when that launch's first waves leave: the work counters
+  // of launches already running were then zeroed under them, their ids handed out a second time, and the duplicates waited
+  // for versions that had passed.  DESIGN.md section 4g.)
+  hipError_t zero_now(void* p, size_t bytes) {
+    hipError_t e = hipMemsetAsync(p, 0, bytes, stream);
+    return e == hipSuccess ? wait_stream(stream) : e;
+  }
+
   int drain() {  // wait for the stream(s) and fold finished launches into the timing totals
     {
       int rc_ = flush_exchange();
@@ -354,10 +363,10 @@ struct rene_ctx {
                        q(st, 0), q(st, .5), q(st, .9), q(st, 1), q(en, 0), q(en, .1), q(en, .5), q(en, .9), q(en, 1));
         }
       }
-      hipMemset(d_wave_times, 0, (size_t)counters_used * 8192 * 2 * 8);
+      zero_now(d_wave_times, (size_t)counters_used * 8192 * 2 * 8);
     }
     if (counters_used) {  // both streams are idle: the work counters can be handed out again
-      HIP_TRY(hipMemset(d_work_counters, 0, kCounters * sizeof(uint32_t)));
+      HIP_TRY(zero_now(d_work_counters, kCounters * sizeof(uint32_t)));
       counters_used = 0;
     }
     // Items whose hand-off did not come were DROPPED by their lanes (device_code.inc: the waves that render the awaited
@@ -374,9 +383,9 @@ struct rene_ctx {
         for (const Pending& p : pending) all = all && p.replayable;
         if (!all) break;  // (the wavefront integrator's launches are not of this kind)
         if (std::getenv("RENE_DEBUG")) std::fprintf(stderr, "[rene] %llu work items were dropped: launching the last %zu launch(es) again, serially (attempt %d)\n", dropped, pending.size(), attempt + 1);
-        HIP_TRY(hipMemset(d_counters + 8, 0, 4 * sizeof(unsigned long long)));
+        HIP_TRY(zero_now(d_counters + 8, 4 * sizeof(unsigned long long)));
         for (Pending& p : pending) {
-          HIP_TRY(hipMemset(d_work_counters, 0, kCounters * sizeof(uint32_t)));
+          HIP_TRY(zero_now(d_work_counters, kCounters * sizeof(uint32_t)));
           rene::RenderParams P = p.P;
           P.flags &= ~rene::RENE_FLAG_INTERNAL_TEST_DROP;
           P.resident = nullptr;
@@ -386,7 +395,7 @@ struct rene_ctx {
           HIP_TRY(wait_stream(stream));
           ++replays;
         }
-        HIP_TRY(hipMemset(d_work_counters, 0, kCounters * sizeof(uint32_t)));
+        HIP_TRY(zero_now(d_work_counters, kCounters * sizeof(uint32_t)));
       }
     }
     while (!pending.empty()) {
@@ -684,6 +693,7 @@ static int rene_create_impl(const rene_scene_desc* scene, const rene_opts* opts,
   HIP_TRY(hipMemsetAsync(c->fb, 0, c->fb_floats * sizeof(float), c->stream));  // main.rs:1229-1237
   HIP_TRY(hipMemsetAsync(c->d_counters, 0, 24 * sizeof(unsigned long long), c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipDeviceSynchronize());  // everything the uploads left on the null stream (the fills of empty tables) has run: see zero_now
 
   if (c->h_upload) {
     hipHostFree(c->h_upload);
@@ -762,7 +772,7 @@ static int rene_render_impl(rene_ctx* c, uint32_t first_frame, uint32_t n_frames
   uint32_t* work_counter = c->d_work_counters + c->counters_used;
   if (std::getenv("RENE_DEBUG") && !c->d_wave_times) {
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_wave_times), (size_t)rene_ctx::kCounters * 8192 * 2 * 8));
-    HIP_TRY(hipMemset(c->d_wave_times, 0, (size_t)rene_ctx::kCounters * 8192 * 2 * 8));
+    HIP_TRY(c->zero_now(c->d_wave_times, (size_t)rene_ctx::kCounters * 8192 * 2 * 8));
   }
   rene_ctx::Pending pend{};
   hipError_t e = hipEventCreate(&pend.start);
