@@ -203,9 +203,9 @@ enum {
   RENE_FLAG_OVERLAP = 1u << 7 /* consecutive rene_render launches alternate between two streams so that one starts while the
                                  previous drains its longest paths; per-pixel ordering is kept on the device (bit-identical
                                  images); rene_sync / rene_download / rene_get_stats / rene_framebuffer join both streams.
-                                 Should the driver park the earlier launch's waves behind the later one's (seen, rarely), the
-                                 later launch drops the work items it waits for and the next sync launches both again, one at
-                                 a time: the image is still bit-identical, the sync takes seconds longer */
+                                 Should a hand-off between two launches ever not come (another process holding wave slots of
+                                 the device, say), the later launch drops the work items it waits for and the next sync
+                                 launches both again, one at a time: the image is still bit-identical, the sync takes longer */
 };
 enum { RENE_SHARD_TILES = 0, RENE_SHARD_FRAMES = 1 };
 
