@@ -382,7 +382,12 @@ struct rene_ctx {
         bool all = true;
         for (const Pending& p : pending) all = all && p.replayable;
         if (!all) break;  // (the wavefront integrator's launches are not of this kind)
-        if (std::getenv("RENE_DEBUG")) std::fprintf(stderr, "[rene] %llu work items were dropped: launching the last %zu launch(es) again, serially (attempt %d)\n", dropped, pending.size(), attempt + 1);
+        if (std::getenv("RENE_DEBUG")) {
+          unsigned long long t[4] = {0, 0, 0, 0};
+          hipMemcpy(t, d_counters + 8, sizeof(t), hipMemcpyDeviceToHost);
+          std::fprintf(stderr, "[rene] %llu work items were dropped (the first: work id %llu of %u slots per level, in launch %llu, wanted version %llu, saw %llu): launching the last %zu launch(es), %u..%u, again, serially (attempt %d)\n",
+                       dropped, t[1], n_work, t[2] >> 32, t[3], t[2] & 0xffffffffull, pending.size(), pending.front().epoch, pending.back().epoch, attempt + 1);
+        }
         HIP_TRY(zero_now(d_counters + 8, 4 * sizeof(unsigned long long)));
         for (Pending& p : pending) {
           HIP_TRY(zero_now(d_work_counters, kCounters * sizeof(uint32_t)));
