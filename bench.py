@@ -6,21 +6,20 @@ fixed spp; achieved rate against the roofline that binds).
 
 Headline workload: BASELINE.json configs[1], "Cornell-box 1024x1024 @ 1024 spp, 1x MI355X" (synthetic
 Cornell-box-shaped scene built in code, rene_amd/scenes.py).  A *step* is one whole such job: clear the
-accumulation image (rene/src/main.rs:1229-1237), render all 1024 frames of every pixel as launches of 256
-frames of the persistent kernel (two launches in flight, RENE_FLAG_OVERLAP), wait for the last launch.  The K timed
-steps are K jobs back to back, each timed on its own as well: `step_ms_median` / `step_ms_min`.  Every job renders the
-same frames, so its image must be bit-identical to the first one's -- checked after the timed region.  Inputs (scene tables,
-BVH, frame seeds) are resident in HBM before the timed region; `value` = rays of all K jobs / elapsed.
+accumulation image (rene/src/main.rs:1229-1237), render all 1024 frames of every pixel -- ONE launch of the persistent
+kernel, every pixel's frames cut into short work items -- and wait for it.  The K timed steps are K
+jobs back to back, each timed on its own as well: `step_ms_median` / `step_ms_min`.  Every job renders the same frames,
+so its image must be bit-identical to the first one's -- checked after the timed region.  Inputs (scene tables, BVH) are
+resident in HBM before the timed region; `value` = rays of all K jobs / elapsed.
 
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL).  Weak scaling (per-GPU work fixed): the job
-becomes an N x 1024 spp image; its frames are dealt to the ranks in N contiguous blocks of 1024
-(rene_amd.dist.frame_block), every rank renders its block exactly as a single GPU renders the headline job, ranks
-never talk while rendering, and the one exchange step of a job -- an RCCL reduce (sum) of the [3][H][W][4] f32 partial
-images onto rank 0 -- is inside the job, hence inside the timed region.  RENE_BENCH_SCALING=strong keeps the job at
-1024 spp (128 frames per rank at N = 8: the fixed costs of a 6 ms share then show); RENE_BENCH_SHARD=tiles selects
-north_star's cut (32x32 tiles round-robin + a gather of owned tiles: bit-identical to one GPU, but a rank's launches
-shrink with N; DESIGN.md section 6 has the measurement behind the default).  value = rays of all ranks /
-max-over-ranks time.
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL).  STRONG scaling by default: the job stays the
+1024-spp image of the N = 1 line; its frames are dealt to the ranks in N contiguous blocks (rene_amd.dist.frame_block:
+128 frames per rank at N = 8, every rank keeps the whole image -- a million pixel chains -- in flight), ranks never talk
+while rendering, and the one exchange step of a job -- an RCCL reduce (sum) of the [3][H][W][4] f32 partial images onto
+rank 0 -- is inside the job, hence inside the timed region.  RENE_BENCH_SHARD=tiles selects north_star's cut instead
+(32x32 tiles round-robin + a gather of owned tiles: bit-identical to one GPU, but a rank's 131 k pixel chains at N = 8 do
+not fill its 393 k lanes; DESIGN.md section 6 has the measurement behind the default).  RENE_BENCH_SCALING=weak renders an
+N x 1024 spp image (1024 frames per rank).  value = rays of all ranks / max-over-ranks time.
 
 The JSON line also carries
   roofline     -- for the dominant kernel of the headline job.  The kernel is bound by VALU issue, not by HBM (the
@@ -29,7 +28,9 @@ The JSON line also carries
                   issue at half rate), `peak` = 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6 T lane-ops/s (a wave64
                   VALU instruction takes a SIMD two cycles; MI355X_MICROARCH.md "Wave scheduling").  Instruction
                   counts per ray come from the committed rocprofv3 PMC passes (profiles/pmc_per_ray.json:
-                  per RAY, so they hold whatever K is); rates are measured live.  `hbm` inside it = the measured
+                  per RAY, so they hold whatever K is; `pmc_stale` says whether the kernel sources have changed since
+                  those passes); rates are measured live.  `useful_lane_frac` = frac x lanes active; `sclk_mhz` = the
+                  engine clock sampled during the timed jobs.  `hbm` inside it = the measured
                   HBM bytes per ray (FETCH_SIZE x 2 + WRITE_SIZE, same passes) x live rays/s against 8 TB/s, and
                   SURVEY 8d's cache-less algorithmic bytes for comparison (not a fraction of anything: the scene
                   lives in the caches).  `traffic` = measured HBM bytes per launch.
@@ -39,7 +40,7 @@ The JSON line also carries
                   Each runs in a process of its own, before this one touches the GPU, under --config-timeout seconds:
                   one that fails or stalls is reported as an error entry and does not take the headline line with it.
   cpu_baseline -- the CPU oracle (a port of rene's integrator; the reference itself has no CPU
-                  path and cannot be built here) timed on this host's cores on a bounded sample.
+                  path and cannot be built here) timed on ALL of this host's hardware threads on a bounded sample.
 """
 from __future__ import annotations
 
@@ -62,18 +63,72 @@ LANES_PER_SIMD_CYCLE = 32  # SIMD-32: a wave64 VALU instruction occupies its SIM
 
 
 def configurations():
-    """name -> (label, scene factory, spp of one job, frames per launch).  The headline is first.
-    Frames per launch from tools/job_shapes.py (overlapped launches, whole jobs): Cornell 128 / 256 / 512 frames -> 44.4 / 44.8 /
-    47.3 ms, dragon-class 64 / 128 / 256 / 512 -> 820 / 796 / 777 / 777 ms, the teapot scene 128 / 256 / 512 / 2048 -> 4.12 / 4.14 /
-    3.89 / 4.08 s, veach-mis flat."""
+    """name -> (label, scene factory, spp of one job, frames per launch).  The headline is first.  One launch per job
+    (tools/job_shapes.py, round 3: Cornell 54.6 ms as one launch of 1024 frames against 55.9 as four serial ones; dragon-class
+    716 against 839 ms; the teapot scene 3.82 against 4.31 s -- a launch boundary is a tail)."""
     from rene_amd import scenes
     return {
-        "cornell": ("cornell-box 1024x1024 @ 1024 spp", lambda: scenes.cornell_box(1024, 1024), 1024, 256),
-        "veach-mis": ("veach-mis 1024x1024 @ 4096 spp", lambda: scenes.veach_mis(1024, 1024), 4096, 256),
-        "dragon-class": ("dragon-class (870 400 triangles, one distant light) 1920x1080 @ 1024 spp", lambda: scenes.dragon_class(1920, 1080), 1024, 256),
+        "cornell": ("cornell-box 1024x1024 @ 1024 spp", lambda: scenes.cornell_box(1024, 1024), 1024, 1024),
+        "veach-mis": ("veach-mis 1024x1024 @ 4096 spp", lambda: scenes.veach_mis(1024, 1024), 4096, 4096),
+        "dragon-class": ("dragon-class (870 400 triangles, one distant light) 1920x1080 @ 1024 spp", lambda: scenes.dragon_class(1920, 1080), 1024, 1024),
         "teapot-class": ("teapot-full-class: rene's sample_scenes/teapot (126 050 triangles, Substrate + checkerboard + env map) through the "
-                         "pbrt loader, synthetic 1024x512 sky, 1920x1080 @ 8192 spp", lambda: scenes.teapot_full(1920, 1080), 8192, 512),
+                         "pbrt loader, synthetic 1024x512 sky, 1920x1080 @ 8192 spp", lambda: scenes.teapot_full(1920, 1080), 8192, 8192),
     }
+
+
+def kernel_source_hash() -> str:
+    """Hash of everything the device code is built from: what the committed PMC passes were taken on (tools/summarize_profiles.py
+    stamps it into profiles/pmc_per_ray.json; a different hash here means the per-ray instruction / byte counts are stale)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "rene_amd", "csrc")
+    for fn in ("device_code.inc", "render_wf.inc", "device_math.h", "device_scene.h", "kernels.hip", "kernels_bvh.hip", "kernels_vol.hip"):
+        h.update(open(os.path.join(d, fn), "rb").read())
+    for line in open(os.path.join(d, "Makefile")):
+        if line.startswith("HIPFLAGS"):
+            h.update(line.encode())
+    return h.hexdigest()[:16]
+
+
+class ClockSampler:
+    """Samples the GPU's engine clock (sysfs pp_dpm_sclk, the entry marked '*') from a thread while the timed jobs run."""
+
+    def __init__(self, device: int):
+        import glob
+        self.paths = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
+        self.path = self.paths[min(device, len(self.paths) - 1)] if self.paths else None
+        self.samples, self._stop, self._t = [], False, None
+
+    def _read(self):
+        try:
+            for line in open(self.path):
+                if "*" in line:
+                    return float(line.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+        except Exception:
+            return None
+        return None
+
+    def _run(self):
+        while not self._stop:
+            v = self._read()
+            if v:
+                self.samples.append(v)
+            time.sleep(0.02)
+
+    def __enter__(self):
+        if self.path:
+            import threading
+            self._t = threading.Thread(target=self._run, daemon=True)
+            self._t.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop = True
+        if self._t:
+            self._t.join(timeout=1.0)
+
+    def median(self):
+        return statistics.median(self.samples) if self.samples else None
 
 
 def pmc_per_ray(name: str):
@@ -94,6 +149,8 @@ def rooflines(name: str, rays_per_s: float, cus: int, alg_bytes_per_ray: float |
         w = rec["valu_wave_insts_per_ray"] + (rec.get("trans_wave_insts_per_ray") or 0.0)  # transcendentals: half rate
         ach = rays_per_s * w * 64.0
         out["valu"] = {"achieved": ach / 1e12, "peak": peak_lane_ops / 1e12, "unit": "Tlane-op/s", "frac": ach / peak_lane_ops,
+                       "useful_lane_frac": ach / peak_lane_ops * rec["valu_lanes_active"] if rec.get("valu_lanes_active") else None,
+                       "pmc_stale": rec.get("kernel_source_hash") != kernel_source_hash(),
                        "lane_ops_per_ray": rec["valu_wave_insts_per_ray"] * 64.0,
                        "trans_lane_ops_per_ray": (rec.get("trans_wave_insts_per_ray") or 0.0) * 64.0,
                        "lanes_active": rec.get("valu_lanes_active"), "wait_any_frac": rec.get("wait_any_frac"),
@@ -123,14 +180,12 @@ def run_config(name: str, device: int = 0):
     import torch
     from rene_amd import abi, api
     lab, mk, spp, fpl = configurations()[name]
-    overlap = abi.FLAG_OVERLAP if os.environ.get("RENE_BENCH_OVERLAP", "1") != "0" else 0
     cus = torch.cuda.get_device_properties(device).multi_processor_count
     sc = mk()
     pk = sc if hasattr(sc, "byref") else sc.to_desc()
     bpr = algorithmic_bytes_per_ray(pk, api, abi, device, frames=2)
-    with api.Renderer(pk, device=device, flags=overlap) as rr:
-        rr.tune(fpl)
-        rr.render(0, fpl)
+    with api.Renderer(pk, device=device) as rr:
+        rr.render(0, min(fpl, 64))
         rr.sync()
         rr.reset()
         t1 = time.perf_counter()
@@ -179,7 +234,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--only", default=None, help="run this configuration as the timed workload instead of the headline (profiling)")
     ap.add_argument("--no-configs", action="store_true", help="skip the additional configurations (C3-C5)")
-    ap.add_argument("--cpu-spp", type=int, default=128, help="frames of the CPU-oracle baseline sample (~10 s on 16 threads)")
+    ap.add_argument("--cpu-spp", type=int, default=128, help="frames of the CPU-oracle baseline sample (~10 s on 16 threads; bounded to ~25 s whatever the host)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--config-child", default=None, help=argparse.SUPPRESS)  # one additional configuration in this process (see configs_in_children)
     ap.add_argument("--config-timeout", type=float, default=300.0, help="seconds an additional configuration may take before it is given up")
@@ -225,29 +280,21 @@ def main():
     n_triangles = api.pack_info(packed).n_triangles
 
     by_tiles = os.environ.get("RENE_BENCH_SHARD", "frames") == "tiles"
-    # N > 1, default: weak scaling -- every GPU renders the headline job's 1024 frames of the whole image (its own frame
-    # range: the job is an N x 1024 spp image), then one reduce.  RENE_BENCH_SCALING=strong keeps the job at 1024 spp and
-    # deals its frames out; the tile cut shrinks a rank's share by construction, so it is always strong.
-    weak = world > 1 and not by_tiles and os.environ.get("RENE_BENCH_SCALING", "weak") != "strong"
+    # N > 1, default: STRONG scaling -- the job is the N = 1 line's (same image, same 1024 spp), its frames dealt to the
+    # ranks in contiguous blocks, then one reduce.  RENE_BENCH_SCALING=weak: every GPU renders 1024 frames of an N x 1024 spp
+    # image.  The tile cut shrinks a rank's share by construction, so it is always strong.
+    weak = world > 1 and not by_tiles and os.environ.get("RENE_BENCH_SCALING", "strong") == "weak"
     JOB_SPP = SPP * world if weak else SPP
     t_rank, t_world = (rank, world) if by_tiles else (0, 1)
     shard = dict(shard_mode=abi.SHARD_TILES, shard_rank=t_rank, shard_count=t_world)
     fb = torch.zeros((3, HEIGHT, WIDTH, 4), dtype=torch.float32, device=f"cuda:{local}")
-    # consecutive launches overlap on two streams (the next one fills the chip while the last paths of the previous
-    # one finish; same image bit for bit) unless RENE_BENCH_OVERLAP=0
-    overlap = abi.FLAG_OVERLAP if os.environ.get("RENE_BENCH_OVERLAP", "1") != "0" else 0
-    r = api.Renderer(packed, device=local, flags=overlap, framebuffer_ptr=fb.data_ptr(), **shard)
-    # this rank's launches of one job: (first_frame, n_frames)
+    r = api.Renderer(packed, device=local, framebuffer_ptr=fb.data_ptr(), **shard)
+    # this rank's launches of one job: (first_frame, n_frames) -- one launch for its whole share
     if by_tiles:
         launches = [(f0, min(F, SPP - f0)) for f0 in range(0, SPP, F)]
     else:
         lo, hi = rdist.frame_block(rank, world, JOB_SPP)
         launches = [(f0, min(F, hi - f0)) for f0 in range(lo, hi, F)]
-        if len(launches) == 1 and launches[0][1] >= 2:
-            # a block that fits one launch is rendered as two: the second starts while the first finishes its longest
-            # paths (measured on one GPU, 128 frames: 8.57 ms as one launch, 8.08 ms as two)
-            f0, nf = launches[0]
-            launches = [(f0, nf // 2), (f0 + nf // 2, nf - nf // 2)]
 
     # The exchange step runs inside the library (rene_reduce / rene_gather_tiles: ncclReduce / ncclSend+Recv on the
     # context's stream); torch.distributed only carries the communicator's 128-byte id and the barriers.  With
@@ -289,9 +336,8 @@ def main():
         if world > 1:
             torch.cuda.synchronize()
 
-    # ---- untimed: algorithmic bytes per ray, work-item granularity (rene_tune; no bit of the image depends on it) ----
+    # ---- untimed: algorithmic bytes per ray (a counting pass over the BVH) ----
     bytes_per_ray = algorithmic_bytes_per_ray(packed, api, abi, local, frames=min(F, 8) if head == "cornell" else 2, **shard)
-    r.tune(max(nf for _, nf in launches))
 
     # ---- warmup (kernel + the collective: RCCL sets its rings up lazily) ----
     for _ in range(Wm):
@@ -307,16 +353,18 @@ def main():
     step_ms, first_image, identical = [], None, True
     kernel_ms, n_launches, rays_job = 0.0, 0, 0
     fence()
-    t0 = time.perf_counter()
-    for k in range(K):
-        t1 = time.perf_counter()
-        job()
-        step_ms.append((time.perf_counter() - t1) * 1e3)
-        if k == 0 or k == K - 1:  # bookkeeping of the first and last job only: a few host-side reads, no device work
-            st = r.stats()
-            kernel_ms, n_launches, rays_job = st.kernel_ms, st.launches, st.rays
-    fence()
-    elapsed = time.perf_counter() - t0
+    with ClockSampler(local) as clock:
+        t0 = time.perf_counter()
+        for k in range(K):
+            t1 = time.perf_counter()
+            job()
+            step_ms.append((time.perf_counter() - t1) * 1e3)
+            if k == 0 or k == K - 1:  # bookkeeping of the first and last job only: a few host-side reads, no device work
+                st = r.stats()
+                kernel_ms, n_launches, rays_job = st.kernel_ms, st.launches, st.rays
+        fence()
+        elapsed = time.perf_counter() - t0
+    sclk = clock.median()
 
     # every job renders the same frames: the last image equals a fresh render of the job, bit for bit (one GPU; with
     # N > 1 the exchange changes rank 0's image in place, compared there as well: the reduce is deterministic)
@@ -353,7 +401,7 @@ def main():
             "n_gpus": n_gpus, "steps": K, "warmup": Wm, "ms_per_step": elapsed / K * 1e3,
             "step_ms_median": statistics.median(step_ms), "step_ms_min": min(step_ms),
             "ms_per_frame": elapsed / (K * JOB_SPP) * 1e3,
-            "higher_is_better": True, "scaling": "weak" if (weak or world == 1) else "strong", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": label, "width": WIDTH, "height": HEIGHT,
                        "spp": JOB_SPP, "spp_per_gpu": JOB_SPP // n_gpus if not by_tiles else JOB_SPP, "frames_per_launch": F, "launches_per_step": len(launches), "triangles": n_triangles,
@@ -366,14 +414,16 @@ def main():
             "rays": total_rays, "rays_per_path": total_rays / (WIDTH * HEIGHT * JOB_SPP * K),
             "jobs_bit_identical": identical,
             "roofline": {"bound": "valu", "achieved": valu["achieved"], "peak": valu["peak"], "unit": valu["unit"],
-                         "frac": valu["frac"], "traffic": traffic,
+                         "frac": valu["frac"], "useful_lane_frac": valu.get("useful_lane_frac"), "traffic": traffic,
                          "kernel": rec.get("kernel", "render_kernel"), "launch_ms": launch_ms,
-                         "launch_period_ms": period_ms, "launches_in_flight": 2 if overlap else 1,
+                         "launch_period_ms": period_ms, "launches_in_flight": 1,
+                         "sclk_mhz": sclk, "pmc_stale": valu.get("pmc_stale"), "kernel_source_hash": kernel_source_hash(),
                          "valu": rl["valu"], "hbm": rl["hbm"],
                          "note": "the scene is cache resident: VALU issue is the roof that binds, priced at 2 cycles per wave64 "
-                                 "VALU instruction on a SIMD-32 (transcendentals 4), nominal 2.4 GHz; rates are the sustained ones "
-                                 "(rays of the timed jobs / elapsed) -- with two launches in flight one launch lasts `launch_ms` "
-                                 "(HIP events; what rocprofv3 reports per dispatch) but one completes every `launch_period_ms`; "
+                                 "VALU instruction on a SIMD-32 (transcendentals 4), nominal 2.4 GHz (`sclk_mhz`: what the clock was "
+                                 "during the timed jobs); rates are the sustained ones (rays of the timed jobs / elapsed); `launch_ms` = "
+                                 "HIP events around the launch, on its stream (what rocprofv3 reports per dispatch); `useful_lane_frac` = "
+                                 "frac x lanes active; `pmc_stale`: the kernel sources differ from the ones the PMC passes ran on; "
                                  "`hbm.frac` is measured HBM traffic (PMC) against 8 TB/s"},
         }
         # ---- the other configurations, one full job each (N = 1 only; measured in child processes before this one started) ----
@@ -382,7 +432,7 @@ def main():
         if n_gpus == 1 and not args.no_cpu_baseline:
             from oracle import oracle  # CPU checker used here only as the reported baseline
             o = oracle.Oracle(packed)
-            threads = min(len(os.sched_getaffinity(0)), 16)  # the CPU share of a 1-GPU box
+            threads = len(os.sched_getaffinity(0))  # all host hardware threads this process may use
             t = time.perf_counter()
             o.render(0, args.cpu_spp, threads=threads)
             dt = time.perf_counter() - t

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RENE_ABI_VERSION 3u
+#define RENE_ABI_VERSION 4u
 
 typedef enum rene_status {
   RENE_OK = 0,
@@ -200,12 +200,11 @@ enum {
                                        random streams stay fp32 / u32.  The image then differs from the fp32 payload's within the
                                        tolerance tests/test_gpu_scenes.py states; ignored by the default integrators, whose ray
                                        payload never leaves the registers */
-  RENE_FLAG_OVERLAP = 1u << 7 /* consecutive rene_render launches alternate between two streams so that one starts while the
-                                 previous drains its longest paths; per-pixel ordering is kept on the device (bit-identical
-                                 images); rene_sync / rene_download / rene_get_stats / rene_framebuffer join both streams.
-                                 Should a hand-off between two launches ever not come (another process holding wave slots of
-                                 the device, say), the later launch drops the work items it waits for and the next sync
-                                 launches both again, one at a time: the image is still bit-identical, the sync takes longer */
+  RENE_FLAG_OVERLAP = 1u << 7 /* accepted and ignored since ABI v4.  (Until v3 consecutive rene_render launches alternated between
+                                 two streams so that one started while the previous drained its longest paths.  One launch now
+                                 renders any number of frames in short work items, so a job is ONE rene_render call with no tail
+                                 between launches to hide, and no launch ever waits for another: the occasional stall of the
+                                 two-stream scheme -- DESIGN.md section 4g -- has nothing left to come from.) */
 };
 enum { RENE_SHARD_TILES = 0, RENE_SHARD_FRAMES = 1 };
 

@@ -93,8 +93,11 @@ RENE_DEV uint32_t pcg_u32(Pcg& r) {  // rand.rs:19-22, 32-36
 // PCG32si::new(master).  Computed where it is needed by jumping the generator ahead (the LCG's g-fold composition by
 // repeated squaring, at most 32 rounds) -- no seed table travels to the device: a launch is a kernel launch and two event
 // records, nothing that needs a copy engine or a free CU slot while persistent kernels hold the chip.
-RENE_DEV uint32_t frame_seed(uint32_t state0, uint32_t g) {
-  uint32_t mul = 747796405u, add = 2891336453u, acc_mul = 1u, acc_add = 0u;
+// g steps of the generator's LCG as one affine map s -> mul * s + add
+RENE_DEV void lcg_pow(uint32_t g, uint32_t& acc_mul, uint32_t& acc_add) {
+  uint32_t mul = 747796405u, add = 2891336453u;
+  acc_mul = 1u;
+  acc_add = 0u;
   for (; g; g >>= 1) {
     if (g & 1u) {
       acc_mul *= mul;
@@ -103,10 +106,17 @@ RENE_DEV uint32_t frame_seed(uint32_t state0, uint32_t g) {
     add = (mul + 1u) * add;
     mul *= mul;
   }
-  const uint32_t s = acc_mul * state0 + acc_add;
+}
+RENE_DEV uint32_t pcg_output(uint32_t s) {  // rand.rs:19-22: the output permutation of a state
   const uint32_t word = ((s >> ((s >> 28) + 4u)) ^ s) * 277803737u;
   return (word >> 22) ^ word;
 }
+RENE_DEV uint32_t frame_state(uint32_t state0, uint32_t g) {
+  uint32_t m, a;
+  lcg_pow(g, m, a);
+  return m * state0 + a;
+}
+RENE_DEV uint32_t frame_seed(uint32_t state0, uint32_t g) { return pcg_output(frame_state(state0, g)); }
 RENE_DEV float pcg_f32(Pcg& r) {  // rand.rs:38-47
   return (1.0f / 16777216.0f) * (float)(pcg_u32(r) >> 8);
 }

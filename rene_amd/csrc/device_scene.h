@@ -179,8 +179,7 @@ constexpr float SMALL_KIND_QUAD = 0.0f, SMALL_KIND_TRIANGLE = 1.0f, SMALL_KIND_S
 //   small_off[SMALL_OFF_ETRI]  EmitTri[] (48 B each)
 //   small_off[SMALL_OFF_SPHERES]  Sphere[] (96 B each): a hit on a sphere, or the pdf of a sphere emitter, reads its matrices
 // A scene whose image would not fit is not FEAT_SMALL (it renders through the BVH kernels).
-constexpr uint32_t SMALL_LDS_MAX_BYTES = 22u * 1024u;  // six workgroups per CU keep image + frame seeds in 160 KB of LDS
-constexpr uint32_t SMALL_LDS_MAX_SEEDS = 1024u;        // a launch's frame seeds follow the image in LDS when it has at most this many frames
+constexpr uint32_t SMALL_LDS_MAX_BYTES = 22u * 1024u;  // six workgroups per CU keep image + seed tables in 160 KB of LDS
 enum : uint32_t { SMALL_OFF_EMIT_ITEMS = 0, SMALL_OFF_HIT, SMALL_OFF_EMIT, SMALL_OFF_EOBJ, SMALL_OFF_ETRI, SMALL_OFF_SPHERES, SMALL_OFF_COUNT };
 constexpr uint32_t SMALL_HIT_FLOATS = 52, SMALL_EMIT_FLOATS = 20;
 
@@ -260,6 +259,35 @@ enum : uint32_t {
                                  // kernels of the two large bench scenes are instantiated without it)
 };
 
+// A pixel record's version: epoch << VERSION_LEVEL_BITS | work items of the pixel committed in that launch.  Ten bits of
+// levels let ONE launch render a whole job in short items (8192 frames in 32-frame items = 256 levels); 22 bits of
+// epoch are four million launches between two clears of the version words (rene_hip.cpp).
+constexpr uint32_t VERSION_LEVEL_BITS = 10;
+constexpr uint32_t MAX_LEVELS = (1u << VERSION_LEVEL_BITS) - 1u;
+constexpr uint32_t MAX_EPOCH = (1u << (32u - VERSION_LEVEL_BITS)) - 1u;
+constexpr uint32_t MAX_LAUNCH_FRAMES = 65536u;  // frames of one launch (its seed tables: SEED_TAB_*); rene_render cuts longer requests
+
+// The launch's frame seeds in LDS.  RenderParams::seed_tab = word offset of the tables in the workgroup's LDS | shift << 24.
+//   shift == 0 (launches of at most SEED_TAB_DIRECT_MAX frames): T[i] = the seed of launch frame i -- one ds_read per path start;
+//   shift >= 5: two levels -- the generator state of launch frame i is T1[i >> shift] pushed on by j = i & (2^shift - 1) frame
+//   steps, T2[j] = (mul, add) being the affine map of j frame steps (a frame step = frame_stride steps of PCG32si's LCG);
+//   T2 (2 * 2^shift words) first, then T1: three ds_reads, a multiply-add and the output permutation per path start,
+//   1.3 KB for a launch of 8192 frames.
+// SEED_TAB_NONE: no room in LDS, every path start composes the jump itself (frame_seed, ~150 integer instructions).
+constexpr uint32_t SEED_TAB_NONE = 0xffffffffu;
+constexpr uint32_t SEED_TAB_DIRECT_MAX = 1024u;
+inline uint32_t seed_tab_shift(uint32_t n_frames) {
+  if (n_frames <= SEED_TAB_DIRECT_MAX) return 0;
+  uint32_t shift = 5;
+  while (((n_frames + (1u << shift) - 1u) >> shift) > 256u) ++shift;
+  return shift;
+}
+inline uint32_t seed_tab_words(uint32_t n_frames) {
+  const uint32_t shift = seed_tab_shift(n_frames);
+  if (shift == 0) return n_frames;
+  return 2u * (1u << shift) + ((n_frames + (1u << shift) - 1u) >> shift);
+}
+
 struct RenderParams {
   float* framebuffer;      // [3][H][W][4]: r, g, b sums + the record's version (device_code.inc, fb_store)
   uint32_t seed_state0;    // state of PCG32si::new(master seed): the seed of global frame g is the stream's g-th output
@@ -273,19 +301,20 @@ struct RenderParams {
   uint32_t shard_rank, shard_count;  // tile sharding (shard_count == 1: all tiles)
   uint32_t tiles_x, n_tiles;
   uint32_t flags;
-  uint32_t n_levels;       // every pixel's frames are cut into n_levels work items of level_step frames (ordered hand-off)
-  uint32_t epoch;          // launch number (1 .. 2^27 - 1); a pixel record's version is epoch << 5 | items committed
+  uint32_t n_levels;       // every pixel's frames are cut into n_levels work items (ordered hand-off): n_uniform items of level_step
+                           // frames, then the rest in halving items (device_code.inc, item_frames)
+  uint32_t epoch;          // launch number (1 .. MAX_EPOCH); a pixel record's version is epoch << VERSION_LEVEL_BITS | items committed
   uint32_t* item_done;     // [n_work] the same versions for the traversal-restart kernels, whose records are 12 bytes
   uint32_t ready_min;      // traversal-restart kernel: lanes waiting before the logic step runs
   uint32_t leaf_min;       // traversal-restart kernel: lanes at a leaf before the leaf step runs
-  uint32_t level_step;     // frames per work item: item (level, pixel) renders frames [level * step, min(F, (level + 1) * step))
+  uint32_t level_step;     // frames per uniform work item: item (level < n_uniform, pixel) renders frames [level * step, (level + 1) * step)
+  uint32_t n_uniform;      // uniform levels; the remaining n_levels - n_uniform levels halve what is left (n_uniform == n_levels: none)
+  uint32_t seed_tab;       // the launch's seed tables in LDS (SEED_TAB_*), set by the launcher
   uint32_t static_waves;   // waves whose first batch is assigned statically (<= co-resident waves)
   uint32_t work_batch;     // work ids a wave takes per global atomic: 128 when items are plentiful, fewer
                            // (down to 16) when a launch has too few items to give every wave a full batch
-  uint32_t prev_final;     // version the context's previous launch leaves on every pixel record (0: a zeroed image):
-                           // what a pixel's first item waits for
-  uint32_t* resident;      // RENE_FLAG_OVERLAP: host-visible [waves]; every wave stores `epoch` here when it starts, so the
-                           // host can tell that the whole launch is resident before it submits the next one (else null)
+  uint32_t prev_final;     // version the context's previous launch left on every pixel record (0: a zeroed image):
+                           // what a pixel's first item continues from (launches are serial: it is there)
   float inv_n_work, inv_tiles_x;  // 1.0f / n_work, 1.0f / tiles_x (udiv_small in the work-item bookkeeping)
   unsigned long long* wave_times;  // RENE_DEBUG: [waves][2] start / end of every wave on the 100 MHz clock, else null
 };

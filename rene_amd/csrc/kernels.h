@@ -10,8 +10,6 @@ namespace rene {
 constexpr uint32_t RENE_FLAG_INTERNAL_TEST_DROP = 1u << 29;  // RenderParams.flags, set by rene_render under RENE_TEST_DROP=<launch>: some items of that
                                                              // launch are dropped as if their hand-off had timed out (tests of the replay)
 
-constexpr uint32_t RENE_FLAG_INTERNAL_SEEDS = 1u << 28;  // RenderParams.flags, set by the launcher: the restart kernel's LDS tables end with the launch's frame seeds
-
 struct LaunchConfig {
   uint32_t features = 0;     // FEAT_* of the scene
   uint32_t stack_depth = 16; // LDS traversal stack entries per lane

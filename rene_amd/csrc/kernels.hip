@@ -182,8 +182,10 @@ static hipError_t launch_small(const LaunchConfig& cfg, const SceneView& S, cons
   RenderParams P = P0;
   auto kernel = count ? render_kernel<FEAT, MAXL, true, true> : (aov ? render_kernel<FEAT, MAXL, false, true> : render_kernel<FEAT, MAXL, false, false>);
   static const size_t lds_pad = std::getenv("RENE_LDS_PAD") ? (size_t)std::atoi(std::getenv("RENE_LDS_PAD")) : 0;  // occupancy experiments
-  // the scene's LDS image (device_scene.h) + the launch's frame seeds
-  const size_t lds = (size_t)S.small_bytes + (P.n_frames <= SMALL_LDS_MAX_SEEDS ? 4u * P.n_frames : 0u) + lds_pad;
+  // the scene's LDS image (device_scene.h) + the launch's seed tables
+  size_t lds = (size_t)S.small_bytes;
+  seed_tables_place(P, lds);
+  lds += lds_pad;
   fit_grid(kernel, lds, cfg, P, grid);
   hipLaunchKernelGGL(kernel, grid, block, lds, st, S, P);
   return hipGetLastError();

@@ -30,12 +30,9 @@ static hipError_t launch_bvh(const LaunchConfig& cfg, const SceneView& S, const 
       kernel = render_kernel_wf<FEAT, MAXL, false, true, true>;
       V.lds_insts = cfg.n_insts;
       lds += tables;
-      if (lds + (size_t)P.n_frames * sizeof(uint32_t) <= 40u * 1024u && !std::getenv("RENE_NO_LDS_SEEDS")) {  // ... and the launch's frame seeds behind them
-        P.flags |= RENE_FLAG_INTERNAL_SEEDS;
-        lds += (size_t)P.n_frames * sizeof(uint32_t);
-      }
     }
   }
+  seed_tables_place(P, lds);
   fit_grid(kernel, lds, cfg, P, grid);
   hipLaunchKernelGGL(kernel, grid, block, lds, st, V, P);
   return hipGetLastError();

@@ -11,6 +11,7 @@ static hipError_t launch_vol(const LaunchConfig& cfg, const SceneView& S, const 
   bool count = (P0.flags & RENE_FLAG_COUNTERS) != 0, aov = !(P0.flags & RENE_FLAG_NO_AOV);
   RenderParams P = P0;
   auto kernel = (count || aov) ? render_kernel<FEAT, MAXL, true, true> : render_kernel<FEAT, MAXL, false, false>;
+  seed_tables_place(P, lds);
   fit_grid(kernel, lds, cfg, P, grid);
   hipLaunchKernelGGL(kernel, grid, block, lds, st, S, P);
   return hipGetLastError();

@@ -12,10 +12,10 @@
 // integrators select volpath (intermediate_scene.rs:1069-1072); Sampler / PixelFilter and all
 // Integrator parameters are ignored (scene.rs:120-128).
 // Spectral colours ("blackbody L" [T scale], "spectrum Kd" "file.spd"; intermediate_scene.rs:272-285, spectrum.rs:1468-1521)
-// are converted with the CIE 1931 matching functions in the analytic form of Wyman, Sloan & Shirley (JCGT 2013) -- the
-// reference tabulates them (pbrt's 471-entry tables) and gets blackbody RGB from the crate `blackbody` 0.0.0, whose source
-// is not in the checkout: this part of the loader is UNPINNED (table vs fit: within a per cent; blackbody: pbrt-v3's own
-// definition, the peak-normalised Planck spectrum).
+// are converted with the CIE 1931 2-degree matching functions at 1 nm (cie1931.inc: the standard's table, which the
+// reference tabulates too) by from_sampled restated in f32, statement for statement: a `.spd` colour equals the
+// reference's.  Blackbody RGB comes from the crate `blackbody` 0.0.0 upstream, whose source is not in the checkout: here it
+// is pbrt-v3's own definition (the peak-normalised Planck spectrum through the same from_sampled) -- that one stays UNPINNED.
 #include <zlib.h>
 #include <algorithm>
 #include <cmath>
@@ -659,36 +659,27 @@ bool get_str(const Object& o, const char* n, std::string& out) {
 // ---- spectral colours -> RGB ---------------------------------------------------------------------------------------
 thread_local std::string g_spd_base_dir;  // directory `spectrum` file names are relative to (set by load_impl)
 
-// CIE 1931 2-degree matching functions, multi-lobe Gaussian fit (Wyman, Sloan, Shirley: "Simple Analytic Approximations
-// to the CIE XYZ Color Matching Functions", JCGT 2(2), 2013)
-void cie_xyz(double l, double xyz[3]) {
-  auto g = [](double x, double mu, double s1, double s2) {
-    const double t = (x - mu) / (x < mu ? s1 : s2);
-    return std::exp(-0.5 * t * t);
-  };
-  xyz[0] = 1.056 * g(l, 599.8, 37.9, 31.0) + 0.362 * g(l, 442.0, 16.0, 26.7) - 0.065 * g(l, 501.1, 20.4, 26.2);
-  xyz[1] = 0.821 * g(l, 568.8, 46.9, 40.5) + 0.286 * g(l, 530.9, 16.3, 31.1);
-  xyz[2] = 1.217 * g(l, 437.0, 11.8, 36.0) + 0.681 * g(l, 459.0, 26.0, 13.8);
-}
-// from_sampled, spectrum.rs:1487-1506: integrate value(lambda) against the matching functions at 360 .. 830 nm in 1 nm
-// steps, normalise by the integral of y, XYZ -> linear sRGB
+// CIE 1931 2-degree matching functions at 360 .. 830 nm in 1 nm steps: the standard's own table (cie1931.inc; the one the
+// reference tabulates, spectrum.rs:5-1467 -- tests/test_spectrum_reference.py holds the two against each other)
+#include "cie1931.inc"
+// from_sampled, spectrum.rs:1487-1506, statement for statement in f32: xyz += value(lambda_i) * matching_i, then
+// scale = (lambda_last - lambda_first) / (CIE_Y_INTEGRAL * N), then XYZ -> linear sRGB
 template <class F>
 void spectrum_to_rgb(F value, float rgb[3]) {
-  double xyz[3] = {0, 0, 0}, y_sum = 0;
-  for (int i = 0; i < 471; ++i) {
-    const double l = 360.0 + i;
-    double m[3];
-    cie_xyz(l, m);
-    const double v = value(l);
-    xyz[0] += v * m[0];
-    xyz[1] += v * m[1];
-    xyz[2] += v * m[2];
-    y_sum += m[1];
+  float x = 0.0f, y = 0.0f, z = 0.0f;
+  for (int i = 0; i < kCieSamples; ++i) {
+    const float val = value(360.0f + (float)i);
+    x += val * kCieX[i];
+    y += val * kCieY[i];
+    z += val * kCieZ[i];
   }
-  for (double& c : xyz) c /= y_sum;
-  rgb[0] = (float)(3.240479 * xyz[0] - 1.537150 * xyz[1] - 0.498535 * xyz[2]);
-  rgb[1] = (float)(-0.969256 * xyz[0] + 1.875991 * xyz[1] + 0.041556 * xyz[2]);
-  rgb[2] = (float)(0.055648 * xyz[0] - 0.204043 * xyz[1] + 1.057311 * xyz[2]);
+  const float scale = (830.0f - 360.0f) / (kCieYIntegral * (float)kCieSamples);
+  x *= scale;
+  y *= scale;
+  z *= scale;
+  rgb[0] = 3.240479f * x - 1.537150f * y - 0.498535f * z;
+  rgb[1] = -0.969256f * x + 1.875991f * y + 0.041556f * z;
+  rgb[2] = 0.055648f * x - 0.204043f * y + 1.057311f * z;
 }
 // "blackbody" [T scale ...]: sum of scale * RGB(peak-normalised Planck spectrum at T) (pbrt-v3's BlackbodyNormalized)
 void blackbody_rgb(const std::vector<float>& pairs, float out[3]) {
@@ -703,7 +694,7 @@ void blackbody_rgb(const std::vector<float>& pairs, float out[3]) {
     };
     const double peak = planck(2.8977721e-3 / T * 1e9);  // Wien's displacement law
     float rgb[3];
-    spectrum_to_rgb([&](double l) { return planck(l) / peak; }, rgb);
+    spectrum_to_rgb([&](float l) { return (float)(planck((double)l) / peak); }, rgb);
     for (int a = 0; a < 3; ++a) out[a] += (float)scale * rgb[a];
   }
 }
@@ -731,18 +722,17 @@ void spd_file_rgb(const std::string& file, float out[3]) {
   // linear extrapolation backwards).  Kept (parity is with the reference's arithmetic); where i + 1 runs off the table
   // the reference panics, here the scene is refused.
   bool off_table = false;
-  spectrum_to_rgb([&](double ld) {
-    const float l = (float)ld;
-    if (l < sp.front().first) return (double)sp.front().second;
-    if (l > sp.back().first) return (double)sp.back().second;
+  spectrum_to_rgb([&](float l) {
+    if (l < sp.front().first) return sp.front().second;
+    if (l > sp.back().first) return sp.back().second;
     size_t i = (size_t)(std::lower_bound(sp.begin(), sp.end(), l, [](const std::pair<float, float>& a, float b) { return a.first < b; }) - sp.begin());
     if (i + 1 >= sp.size()) {
-      if (sp[i].first == l) return (double)sp[i].second;  // an exact hit on the last sample: t = 0 never reads sample i + 1 ... in exact arithmetic
+      if (sp[i].first == l) return sp[i].second;  // an exact hit on the last sample: t = 0 never reads sample i + 1 ... in exact arithmetic
       off_table = true;
-      return 0.0;
+      return 0.0f;
     }
     const float t = (l - sp[i].first) / (sp[i + 1].first - sp[i].first);
-    return (double)((1.0f - t) * sp[i].second + t * sp[i + 1].second);
+    return (1.0f - t) * sp[i].second + t * sp[i + 1].second;
   }, out);
   if (off_table) fail(RENE_ERR_INVALID_SCENE, "spectrum file " + path + ": a CIE wavelength falls into its last segment (the reference indexes past the table there)");
 }

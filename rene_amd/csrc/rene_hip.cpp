@@ -97,17 +97,24 @@ Rccl* rccl() {
   static Rccl* r = [] {
     Rccl* x = new Rccl();
     // a process that already holds an RCCL (PyTorch ships its own copy) uses that one; else the ROCm installation's
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // (RENE_RCCL_LIB=<path> names the library instead: hosts that keep it elsewhere, and the test of the missing-library path)
+    const char* over = std::getenv("RENE_RCCL_LIB");
+    const char* defaults[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    std::vector<const char*> names;
+    if (over && *over) names.push_back(over);
+    else names.assign(defaults, defaults + 3);
     for (const char* n : names) {
       x->handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
       if (x->handle) break;
     }
+    const char* why = nullptr;
     for (const char* n : names) {
       if (x->handle) break;
       x->handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+      if (!x->handle && !why) why = dlerror();  // dlerror() clears the message it returns: read it once
     }
     if (!x->handle) {
-      x->error = std::string("RCCL is not available: ") + (dlerror() ? dlerror() : "librccl.so not found");
+      x->error = std::string("RCCL is not available: ") + (why ? why : "librccl.so not found");
       return x;
     }
     bool ok = true;
@@ -172,13 +179,6 @@ struct rene_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
-  // RENE_FLAG_OVERLAP: consecutive launches alternate between `stream` and `stream2`, so that a launch starts
-  // filling the chip while the previous one drains its longest paths (its own work counter each; the kernels
-  // order the two launches' updates of a pixel through the version its records carry, device_code.inc item_load)
-  hipStream_t stream2 = nullptr;
-  hipEvent_t join_event = nullptr;
-  uint32_t* h_resident = nullptr;   // pinned, one word per wave of a launch (RenderParams::resident)
-  uint32_t resident_words = 0;
   rene_opts opts{};
   std::vector<void*> allocations;
   rene::SceneView view{};
@@ -192,10 +192,9 @@ struct rene_ctx {
   unsigned long long* d_wave_times = nullptr; // RENE_DEBUG: [kCounters][8192][2]
   uint32_t counters_used = 0;
   uint32_t epoch = 0, prev_final = 0;
-  // frames per work item: kWholeLaunch = one item per pixel and launch; 0 = not tuned (rene_tune picks): four items per
-  // pixel for the item-loop kernels, whose item switches cost one memory round trip, eight for the BVH kernels, where
-  // untuned scenes have more to lose from unbalanced pixels (dragon-class 6.0 -> 7.9 Grays/s) than from the
-  // bookkeeping (teapot-class 6.8 -> 6.7)
+  // frames per work item: kWholeLaunch = one item per pixel and launch; 0 = not tuned (rene_tune picks): 64 for the
+  // item-loop kernels, whose item switches cost a memory round trip of the whole wave, 32 for the BVH kernels, where
+  // pixels differ more in cost and a lane that waits is a lane the ballots miss
   static constexpr uint32_t kWholeLaunch = 0xffffffffu;
   uint32_t item_frames = 0;
   std::vector<uint32_t> inst_material;  // material index of every instance (rene_bsdf_eval looks an instance of its material up)
@@ -208,22 +207,12 @@ struct rene_ctx {
   // per-launch resources that must outlive the asynchronous launch
   struct Pending {
     hipEvent_t start, stop;
-    bool second_stream;
-    uint32_t epoch, waves;
+    uint32_t epoch;
     bool replayable = false;    // a persistent render launch: what it was launched with, should it have to be launched again
     rene::RenderParams P{};
     rene::LaunchConfig cfg{};
   };
   uint64_t replays = 0;         // launches launched again by drain() (RENE_DEBUG prints them)
-  bool overlap() const { return stream2 != nullptr; }
-  // order everything launched on stream2 before whatever is enqueued on `stream` next (callers that handed in their
-  // own stream consume the framebuffer there)
-  hipError_t join() {
-    if (!stream2) return hipSuccess;
-    hipError_t e = hipEventRecord(join_event, stream2);
-    if (e == hipSuccess) e = hipStreamWaitEvent(stream, join_event, 0);
-    return e;
-  }
   std::deque<Pending> pending;
   uint64_t frames = 0, launches = 0, owned_pixels = 0, paths = 0;
   double kernel_ms = 0.0, last_ms = 0.0;
@@ -265,51 +254,6 @@ struct rene_ctx {
     return RENE_OK;
   }
 
-  // RENE_FLAG_OVERLAP, before a launch is submitted to one of the two streams: (1) the previous launch on that stream
-  // has completed -- stream order would see to that, but the host must not run further ahead either; (2) every wave
-  // of the launch before this one (the other stream's) is resident, or that launch is over.  The new launch can then
-  // only be given the slots its predecessor's waves vacate.  Without (2) two launches submitted to an idle device
-  // start together, the later one may take every slot and wait there for pixels the earlier one can no longer reach.
-  int admit(bool second_stream) {
-    const Pending* same = nullptr;
-    for (auto it = pending.rbegin(); it != pending.rend(); ++it)
-      if (it->second_stream == second_stream) { same = &*it; break; }
-    if (same) HIP_TRY(wait_event(same->stop));
-    if (pending.empty() || pending.back().second_stream == second_stream) return RENE_OK;
-    const Pending& prev = pending.back();
-    const auto t0 = std::chrono::steady_clock::now();
-    if (std::getenv("RENE_DEBUG")) {
-      uint32_t n_eq = 0, n_other = 0, first_other = 0;
-      for (uint32_t w = 0; w < prev.waves; ++w) {
-        const uint32_t v = __atomic_load_n(&h_resident[w], __ATOMIC_ACQUIRE);
-        if (v == prev.epoch) n_eq++;
-        else if (!n_other++) first_other = v;
-      }
-      std::fprintf(stderr, "[rene] admit: launch %u has %u waves; at entry %u announce it, %u hold another value (e.g. %u); h_resident %p\n", prev.epoch, prev.waves, n_eq, n_other, first_other, (void*)h_resident);
-    }
-    for (uint64_t spins = 0;; ++spins) {
-      bool all = true;
-      for (uint32_t w = 0; w < prev.waves && all; ++w)
-        all = __atomic_load_n(&h_resident[w], __ATOMIC_ACQUIRE) == prev.epoch;
-      if (all) {
-        if (std::getenv("RENE_DEBUG")) std::fprintf(stderr, "[rene] admit: launch %u resident after %.3f ms\n", prev.epoch, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-        return RENE_OK;
-      }
-      if ((spins & 63u) == 63u) {
-        if (hipEventQuery(prev.stop) == hipSuccess) {
-          if (std::getenv("RENE_DEBUG")) std::fprintf(stderr, "[rene] admit: launch %u already over\n", prev.epoch);
-          return RENE_OK;  // it has come and gone
-        }
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
-          if (std::getenv("RENE_DEBUG")) std::fprintf(stderr, "[rene] admit: launch %u not resident after 200 ms, waiting for it\n", prev.epoch);
-          // a device shared with other work may keep part of that launch out for long: then simply let it finish
-          HIP_TRY(wait_event(prev.stop));
-          return RENE_OK;
-        }
-      }
-    }
-  }
-
   // root of a rene_gather_tiles: place the other ranks' tiles (enqueued behind the receives on `stream`)
   int flush_exchange() {
     if (unpack_root < 0) return RENE_OK;
@@ -342,7 +286,6 @@ struct rene_ctx {
       if (rc_ != RENE_OK) return rc_;
     }
     HIP_TRY(wait_stream(stream));
-    if (stream2) HIP_TRY(wait_stream(stream2));
     const bool had_launches = !pending.empty();
     if (counters_used && d_wave_times) {  // RENE_DEBUG: per launch, when its waves started and ended (ms since the first start)
       std::vector<unsigned long long> t((size_t)counters_used * 8192 * 2);
@@ -365,7 +308,7 @@ struct rene_ctx {
       }
       zero_now(d_wave_times, (size_t)counters_used * 8192 * 2 * 8);
     }
-    if (counters_used) {  // both streams are idle: the work counters can be handed out again
+    if (counters_used) {  // the stream is idle: the work counters can be handed out again
       HIP_TRY(zero_now(d_work_counters, kCounters * sizeof(uint32_t)));
       counters_used = 0;
     }
@@ -393,11 +336,12 @@ struct rene_ctx {
           HIP_TRY(zero_now(d_work_counters, kCounters * sizeof(uint32_t)));
           rene::RenderParams P = p.P;
           P.flags &= ~rene::RENE_FLAG_INTERNAL_TEST_DROP;
-          P.resident = nullptr;
           rene::g_launched_blocks = p.cfg.grid;
+          const auto tr = std::chrono::steady_clock::now();
           hipError_t e = rene::launch_render(p.cfg, view, P, stream);
           if (e != hipSuccess) return fail(RENE_ERR_DEVICE, std::string("render launch (replay): ") + hipGetErrorString(e));
           HIP_TRY(wait_stream(stream));
+          kernel_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr).count();  // rene_stats.launches counts it too
           ++replays;
         }
         HIP_TRY(zero_now(d_work_counters, kCounters * sizeof(uint32_t)));
@@ -688,13 +632,6 @@ static int rene_create_impl(const rene_scene_desc* scene, const rene_opts* opts,
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_counters), 24 * sizeof(unsigned long long)));
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_item_done), std::max<size_t>(1, c->n_work) * sizeof(uint32_t)));
   HIP_TRY(hipMemsetAsync(c->d_item_done, 0, std::max<size_t>(1, c->n_work) * sizeof(uint32_t), c->stream));
-  if ((o.flags & RENE_FLAG_OVERLAP) && !c->wavefront) {
-    HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&c->join_event, hipEventDisableTiming));
-    c->resident_words = c->cfg.grid * (uint32_t)(rene::render_block_size() / 64);
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_resident), c->resident_words * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
-    std::memset(c->h_resident, 0, c->resident_words * sizeof(uint32_t));
-  }
   HIP_TRY(hipMemsetAsync(c->fb, 0, c->fb_floats * sizeof(float), c->stream));  // main.rs:1229-1237
   HIP_TRY(hipMemsetAsync(c->d_counters, 0, 24 * sizeof(unsigned long long), c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -713,7 +650,6 @@ void rene_destroy(rene_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
-  if (c->stream2) hipStreamSynchronize(c->stream2);
   for (auto& p : c->pending) {
     hipEventDestroy(p.start);
     hipEventDestroy(p.stop);
@@ -722,12 +658,9 @@ void rene_destroy(rene_ctx* c) {
   if (c->own_fb && c->fb) hipFree(c->fb);
   if (c->d_work_counters) hipFree(c->d_work_counters);
   if (c->d_wave_times) hipFree(c->d_wave_times);
-  if (c->join_event) hipEventDestroy(c->join_event);
-  if (c->stream2) hipStreamDestroy(c->stream2);
   if (c->d_counters) hipFree(c->d_counters);
   if (c->d_item_done) hipFree(c->d_item_done);
   if (c->h_done) hipHostFree(c->h_done);
-  if (c->h_resident) hipHostFree(c->h_resident);
   if (c->h_stage) hipHostFree(c->h_stage);
   if (c->h_upload) hipHostFree(c->h_upload);
   if (c->tile_buf) hipFree(c->tile_buf);
@@ -741,6 +674,15 @@ static int rene_render_impl(rene_ctx* c, uint32_t first_frame, uint32_t n_frames
   if (n_frames == 0) return RENE_OK;
   if (c->exchanged) return fail(RENE_ERR_INVALID_ARGUMENT, "the image has been through rene_reduce / rene_gather_tiles: rene_reset before rendering again");
   if ((uint64_t)first_frame + n_frames > 0xffffffffull) return fail(RENE_ERR_INVALID_ARGUMENT, "frame range overflows u32");
+  if (n_frames > rene::MAX_LAUNCH_FRAMES) {  // one launch renders at most this many frames (its seed tables)
+    for (uint32_t done = 0; done < n_frames;) {
+      const uint32_t n = std::min(rene::MAX_LAUNCH_FRAMES, n_frames - done);
+      int rc = rene_render_impl(c, first_frame + done, n);
+      if (rc != RENE_OK) return rc;
+      done += n;
+    }
+    return RENE_OK;
+  }
   HIP_TRY(hipSetDevice(c->device));
   // which frames of [first_frame, first_frame + n_frames) are this context's: all of them, or under RENE_SHARD_FRAMES those
   // with f % shard_count == shard_rank.  The kernels compute the frames' seeds themselves (device_math.h, frame_seed).
@@ -756,7 +698,7 @@ static int rene_render_impl(rene_ctx* c, uint32_t first_frame, uint32_t n_frames
   if (my_count == 0 || c->n_work == 0) return RENE_OK;
   c->paths += (uint64_t)my_count * c->owned_pixels;
 
-  if (c->epoch >= (1u << 27) - 1u) {  // the hand-off flags are cleared when the epoch wraps: nothing may be in flight then
+  if (c->epoch >= rene::MAX_EPOCH) {  // the hand-off flags are cleared when the epoch wraps: nothing may be in flight then
     int rc = c->drain();
     if (rc != RENE_OK) return rc;
   }
@@ -767,13 +709,12 @@ static int rene_render_impl(rene_ctx* c, uint32_t first_frame, uint32_t n_frames
     int rc = c->drain();
     if (rc != RENE_OK) return rc;
   }
-  // odd launches of an overlapping context go to the second stream
-  const bool second_stream = c->overlap() && (c->epoch & 1u);
-  if (c->overlap()) {
-    int rc = c->admit(second_stream);
-    if (rc != RENE_OK) return rc;
-  }
-  hipStream_t stream = second_stream ? c->stream2 : c->stream;
+  // Launches are serial on the context's one stream.  (Rounds 1-2 alternated consecutive launches between two streams so that
+  // the next launch filled the slots the previous one's tail vacated; the waves of the later launch then waited, holding
+  // their slots, for pixels of the earlier one -- and when the driver evicted and restored the process's queues, the earlier
+  // launch's waves could find their slots taken: a stall of seconds, DESIGN.md section 4g.  One launch per job in short work
+  // items has the same tail to hide -- none between launches -- and no launch ever waits for another.)
+  hipStream_t stream = c->stream;
   uint32_t* work_counter = c->d_work_counters + c->counters_used;
   if (std::getenv("RENE_DEBUG") && !c->d_wave_times) {
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_wave_times), (size_t)rene_ctx::kCounters * 8192 * 2 * 8));
@@ -791,7 +732,6 @@ static int rene_render_impl(rene_ctx* c, uint32_t first_frame, uint32_t n_frames
   P.work_counter = work_counter;
   P.wave_times = c->d_wave_times ? c->d_wave_times + (size_t)c->counters_used * 8192 * 2 : nullptr;
   P.item_done = c->d_item_done;
-  P.resident = std::getenv("RENE_NO_ANNOUNCE") ? nullptr : c->h_resident;  // host-coherent memory: the same pointer is valid on the device
   P.counters = c->d_counters;
   P.n_frames = my_count;
   P.n_work = c->n_work;
@@ -811,17 +751,47 @@ static int rene_render_impl(rene_ctx* c, uint32_t first_frame, uint32_t n_frames
   P.flags |= RENE_FLAG_DYNAMIC_FIRST;
   if (const char* e = std::getenv("RENE_TEST_DROP"))  // fault injection (tests): the context's launch number e drops some of its items
     if ((uint32_t)std::atoi(e) == c->epoch + 1u) P.flags |= rene::RENE_FLAG_INTERNAL_TEST_DROP;
-  // every pixel's frames in `levels` work items of `step` frames (device_code.inc, render_kernel)
-  uint32_t levels = (c->cfg.features & rene::FEAT_SMALL) ? 4u : 8u;
-  if (c->item_frames == rene_ctx::kWholeLaunch) levels = 1;
-  else if (c->item_frames) levels = std::min(31u, (P.n_frames + c->item_frames - 1) / c->item_frames);
-  if (const char* e = std::getenv("RENE_LEVELS")) levels = (uint32_t)std::max(1, std::min(31, std::atoi(e)));  // tuning knob
-  if ((c->opts.flags & RENE_FLAG_SINGLE_LEVEL) || P.n_frames < 4) levels = 1;
-  levels = std::min(levels, P.n_frames);
-  P.level_step = (P.n_frames + levels - 1) / levels;
-  P.n_levels = (P.n_frames + P.level_step - 1) / P.level_step;
+  // every pixel's frames in work items (device_code.inc, item_frames): uniform items of `item` frames, the last one or two of
+  // them cut into halving items down to `tail` frames; RENE_LEVELS=<n> (tests, A/B measurements) cuts into n uniform items
+  {
+    const uint32_t F = P.n_frames;
+    uint32_t item = c->item_frames ? c->item_frames : ((c->cfg.features & rene::FEAT_SMALL) ? 64u : 32u);
+    uint32_t tail = (c->cfg.features & rene::FEAT_SMALL) ? 8u : 4u;
+    if (const char* e = std::getenv("RENE_ITEM_FRAMES")) item = (uint32_t)std::max(1, std::atoi(e));  // tuning knobs
+    if (const char* e = std::getenv("RENE_ITEM_TAIL")) tail = (uint32_t)std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("RENE_LEVELS")) {
+      const uint32_t levels = std::min((uint32_t)std::max(1, std::min((int)rene::MAX_LEVELS, std::atoi(e))), F);
+      item = (F + levels - 1) / levels;
+      tail = item;
+    }
+    if (c->item_frames == rene_ctx::kWholeLaunch || (c->opts.flags & RENE_FLAG_SINGLE_LEVEL) || F < 4) item = tail = F;
+    // work ids are 32-bit (level * n_work + slot < 2^31) and a version counts at most MAX_LEVELS items
+    const uint32_t max_levels = std::max(1u, std::min(rene::MAX_LEVELS, (uint32_t)(0x7fffffffu / std::max(1u, c->n_work))));
+    item = std::min(std::max(item, 1u), F);
+    for (;;) {
+      uint32_t K = F / item, R = F - K * item, H = R ? 1u : 0u;  // K uniform items, then H halving items over the rest R
+      if (tail < item && F >= 2 * item) {  // the last uniform item joins the rest: R in [item, 2 item)
+        K -= 1;
+        R += item;
+        H = 1;
+        while (H < 16u && (R >> H) >= tail) ++H;  // the last one has ceil(R / 2^(H-1)) >= tail frames
+      } else if (tail < item && K == 1 && R == 0) {  // a launch of one item's length: halve that
+        K = 0;
+        R = F;
+        H = 1;
+        while (H < 16u && (R >> H) >= tail) ++H;
+      }
+      if (K + H <= max_levels) {
+        P.level_step = item;
+        P.n_uniform = K;
+        P.n_levels = K + H;
+        break;
+      }
+      item += (item + 7) / 8;  // too many levels: longer items
+    }
+  }
   P.prev_final = c->prev_final;
-  if (c->epoch >= (1u << 27) - 1u) {  // (drained above) the epoch wraps: every pixel record back to version 0
+  if (c->epoch >= rene::MAX_EPOCH) {  // (drained above) the epoch wraps: every pixel record back to version 0
     hipMemset2DAsync(c->fb + 3, 4 * sizeof(float), 0, sizeof(float), c->fb_floats / 4, stream);
     hipMemsetAsync(c->d_item_done, 0, std::max<size_t>(1, c->n_work) * sizeof(uint32_t), stream);
     c->epoch = 0;
@@ -829,7 +799,7 @@ static int rene_render_impl(rene_ctx* c, uint32_t first_frame, uint32_t n_frames
   }
   const uint32_t saved_epoch = c->epoch, saved_prev_final = c->prev_final;
   P.epoch = ++c->epoch;
-  c->prev_final = (P.epoch << 5) | P.n_levels;
+  c->prev_final = (P.epoch << rene::VERSION_LEVEL_BITS) | P.n_levels;
   // swept with the BVH4 (tools/dev_sweep4.py): dragon-class (Matte) peaks at 24 / 12 (4.96 Grays/s; 20 / 16 gave 4.6);
   // teapot-class, whose logic step is the general-BSDF one, keeps gaining up to ~44 waiting lanes (5.3 vs 4.7)
   P.ready_min = (c->cfg.features & rene::FEAT_GENERAL_BSDF) ? 40 : 24;
@@ -879,21 +849,24 @@ static int rene_render_impl(rene_ctx* c, uint32_t first_frame, uint32_t n_frames
   hipEventRecord(pend.start, stream);
   rene::g_launched_blocks = cfg.grid;
   e = rene::launch_render(cfg, c->view, P, stream);
+  if (e != hipSuccess) {
+    // nothing was launched: no pending entry (a replay must not launch what the caller was told failed), no counter slot,
+    // and the next launch must not wait for versions this one would have written
+    hipEventDestroy(pend.start);
+    hipEventDestroy(pend.stop);
+    c->epoch = saved_epoch;
+    c->prev_final = saved_prev_final;
+    c->frames -= n_frames;
+    c->paths -= (uint64_t)my_count * c->owned_pixels;
+    return fail(RENE_ERR_DEVICE, std::string("render launch: ") + hipGetErrorString(e));
+  }
   hipEventRecord(pend.stop, stream);
-  pend.second_stream = second_stream;
   pend.epoch = P.epoch;
   pend.replayable = true;
   pend.P = P;
   pend.cfg = cfg;
   c->counters_used++;
-  pend.waves = std::min(rene::g_launched_blocks * (uint32_t)(rene::render_block_size() / 64), c->resident_words);
   c->pending.push_back(pend);
-  if (e != hipSuccess) {
-    // nothing was launched: the next launch must not wait for versions this one would have written
-    c->epoch = saved_epoch;
-    c->prev_final = saved_prev_final;
-    return fail(RENE_ERR_DEVICE, std::string("render launch: ") + hipGetErrorString(e));
-  }
   c->launches++;
   if (c->pending.size() >= rene_ctx::kCounters) return c->drain();
   return RENE_OK;
@@ -920,6 +893,7 @@ int rene_reset(rene_ctx* c) {
   c->frames = 0;
   c->paths = 0;
   c->launches = 0;
+  c->replays = 0;
   c->kernel_ms = 0.0;
   c->last_ms = 0.0;
   return RENE_OK;
@@ -934,24 +908,27 @@ int rene_tune(rene_ctx* c, uint32_t n_frames) {
   const uint32_t saved = c->item_frames;
   uint32_t best = saved;
   double best_ms = 0.0;
-  for (uint32_t levels = 1; levels <= 16 && levels <= n_frames; levels *= 2) {
-    c->item_frames = levels == 1 ? rene_ctx::kWholeLaunch : (n_frames + levels - 1) / levels;
+  // candidates: one item per pixel and launch, then items of 128 / 64 / 32 / 16 frames (their last ones halving, rene_render)
+  const uint32_t items[5] = {rene_ctx::kWholeLaunch, 128u, 64u, 32u, 16u};
+  for (int i = 0; i < 5; ++i) {
+    if (i > 0 && items[i] * 2u > n_frames) continue;
+    c->item_frames = items[i];
     const auto t0 = std::chrono::steady_clock::now();
-    for (int k = 0; k < 4 && rc == RENE_OK; ++k) rc = rene_render(c, 0, n_frames);  // what is rendered does not matter
+    for (int k = 0; k < 3 && rc == RENE_OK; ++k) rc = rene_render(c, 0, n_frames);  // what is rendered does not matter
     if (rc == RENE_OK) rc = c->drain();
     if (rc != RENE_OK) {
       c->item_frames = saved;
       return rc;
     }
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    if (levels == 1 || ms < 0.985 * best_ms) {  // finer items must pay for their bookkeeping
+    if (i == 0 || ms < 0.985 * best_ms) {  // finer items must pay for their bookkeeping
       best_ms = ms;
       best = c->item_frames;
     }
   }
   c->item_frames = best;
   if (std::getenv("RENE_DEBUG"))
-    std::fprintf(stderr, "[rene] tuned: %u frames per work item for launches of %u frames\n", best == rene_ctx::kWholeLaunch ? n_frames : best, n_frames);
+    std::fprintf(stderr, "[rene] tuned: work items of %u frames for launches of %u frames\n", best == rene_ctx::kWholeLaunch ? n_frames : best, n_frames);
   return rene_reset(c);
 }
 
@@ -960,7 +937,6 @@ int rene_framebuffer(rene_ctx* c, void** device_ptr, size_t* n_floats) {
   *device_ptr = c->fb;
   if (n_floats) *n_floats = c->fb_floats;
   HIP_TRY(hipSetDevice(c->device));
-  if (c->overlap()) HIP_TRY(c->join());  // what the caller enqueues on the context's stream next comes after every launch
   return c->flush_exchange();
 }
 
@@ -1212,7 +1188,10 @@ int rene_reduce(rene_ctx* c, int root) {
   if (root < 0 || root >= c->comm_ranks) return fail(RENE_ERR_INVALID_ARGUMENT, "rene_reduce: root out of range");
   Rccl* R = rccl();
   HIP_TRY(hipSetDevice(c->device));
-  HIP_TRY(c->join());  // the collective runs on `stream`, behind every launch of both streams
+  {  // every launch has completed (and any dropped work item has been rendered by a replay) before the image is summed
+    int rc = c->drain();
+    if (rc != RENE_OK) return rc;
+  }
   c->exchanged = true;
   RCCL_TRY(R->Reduce(c->fb, c->fb, c->fb_floats, ncclFloat, ncclSum, root, c->comm, c->stream));
   return RENE_OK;
@@ -1227,7 +1206,10 @@ int rene_gather_tiles(rene_ctx* c, int root) {
     return fail(RENE_ERR_INVALID_ARGUMENT, "rene_gather_tiles: the context must be tile-sharded with shard_count == n_ranks and shard_rank == rank");
   Rccl* R = rccl();
   HIP_TRY(hipSetDevice(c->device));
-  HIP_TRY(c->join());
+  {  // as rene_reduce: what is packed and sent is a complete image
+    int rc = c->drain();
+    if (rc != RENE_OK) return rc;
+  }
   c->exchanged = true;
   const size_t tile_floats = (size_t)3 * RENE_TILE_SIZE * RENE_TILE_SIZE * 4;
   auto owned = [&](uint32_t r) { return c->n_tiles > r ? (c->n_tiles - r + n - 1) / n : 0u; };

@@ -4,6 +4,7 @@ import ctypes as C
 import os
 import re
 import subprocess
+import sys
 import tempfile
 
 import numpy as np
@@ -205,3 +206,20 @@ def test_item_merging_counts_on_the_host(hip_lib):
             s.add_triangle_mesh(TriangleMesh.from_arrays([k, 0, 3, k + 0.5, 0, 3, k, 1, 3], [0, 1, 2]), m(s))
     i = info(many)
     assert i.n_items_main == 0 and not (i.features & 64)
+
+
+def test_missing_rccl_is_an_error_code_not_a_crash():
+    """ADVICE r2: with no RCCL to load, rene_comm_unique_id returns RENE_ERR_UNSUPPORTED with a message (dlerror() is read once;
+    reading it twice handed std::string a NULL).  A fresh process, because the library looks for RCCL once."""
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from rene_amd import api\n"
+            "try:\n"
+            "    api.comm_unique_id()\n"
+            "    print('LOADED')\n"
+            "except api.ReneError as e:\n"
+            "    print('CODE', e.code, '|', str(e))\n" % ROOT)
+    env = dict(os.environ, RENE_RCCL_LIB="/nonexistent/librccl-absent.so")
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr[-500:]
+    assert "CODE -4" in p.stdout and "RCCL is not available" in p.stdout and "librccl-absent" in p.stdout, p.stdout

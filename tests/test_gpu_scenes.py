@@ -214,6 +214,20 @@ def test_every_work_item_cut_and_rene_tune_give_the_same_bits(name, monkeypatch)
             assert {k: got[k] for k in ("paths", "rays_closest", "rays_shadow", "rays_emitter", "adds")} == \
                    {k: st[k] for k in ("paths", "rays_closest", "rays_shadow", "rays_emitter", "adds")}
     monkeypatch.delenv("RENE_LEVELS")
+    # the default cut: uniform items whose last ones halve (13 frames, items of 4 down to 1: 4 4 | 3 1 1; items of 13 down to 2: 7 3 3)
+    for item, tail in (("4", "1"), ("13", "2"), ("5", "5"), ("3", "2"), ("64", "8")):
+        monkeypatch.setenv("RENE_ITEM_FRAMES", item)
+        monkeypatch.setenv("RENE_ITEM_TAIL", tail)
+        with api.Renderer(s, flags=abi.FLAG_COUNTERS) as r:
+            r.render(0, 13)
+            r.render(13, 7)
+            for k in range(3):
+                np.testing.assert_array_equal(r.download(k), want[k], err_msg=f"items of {item} frames halving to {tail}, layer {k}")
+            got = r.stats().as_dict()
+            assert {k: got[k] for k in ("paths", "rays_closest", "rays_shadow", "rays_emitter", "adds")} == \
+                   {k: st[k] for k in ("paths", "rays_closest", "rays_shadow", "rays_emitter", "adds")}
+    monkeypatch.delenv("RENE_ITEM_FRAMES")
+    monkeypatch.delenv("RENE_ITEM_TAIL")
     for flags in (0, abi.FLAG_OVERLAP):
         with api.Renderer(s, flags=flags) as r:
             r.render(0, 3)  # something to be discarded

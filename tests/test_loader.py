@@ -442,7 +442,8 @@ def test_spd_file_colours(tmp_path, hip_lib):
     reference's segment indexing is kept, including where it runs off the table."""
     (tmp_path / "flat.spd").write_text("".join(f"{l} 1.0\n" for l in (300, 500, 700, 850, 900)))
     L = _light_L(_SPEC_SCENE % '"spectrum L" "flat.spd"', tmp_path)
-    assert abs(0.212671 * L[0] + 0.715160 * L[1] + 0.072169 * L[2] - 1.0) < 2e-3  # luminance of white
+    # luminance of white: from_sampled scales by (830 - 360) / (CIE_Y_INTEGRAL * 471), i.e. Y = 470 / 471 (spectrum.rs:1497-1498)
+    assert abs(0.212671 * L[0] + 0.715160 * L[1] + 0.072169 * L[2] - 470.0 / 471.0) < 1e-3
     np.testing.assert_allclose(L, [1.205, 0.948, 0.909], atol=0.02)                # equal-energy white in linear sRGB
     # a smooth green bump sampled every 5 nm (the shifted-segment lookup then costs little): green dominates
     (tmp_path / "green.spd").write_text("".join(f"{l} {np.exp(-0.5 * ((l - 535) / 25.0) ** 2):.6f}\n" for l in range(300, 905, 5)))

@@ -132,6 +132,9 @@ def main():
             rec["scalar_cache_req_per_ray"] = per_ray["SQC_DCACHE_REQ"]
             rec["scalar_cache_miss_rate"] = per_ray.get("SQC_DCACHE_MISSES", 0.0) / per_ray["SQC_DCACHE_REQ"]
         rec["mrays_per_s_during_passes"] = {k[6:]: v for k, v in per_ray.items() if k.startswith("_rate_")}
+        sys.path.insert(0, ROOT)
+        import bench  # the hash of the kernel sources these passes ran on (bench.py: `pmc_stale`)
+        rec["kernel_source_hash"] = bench.kernel_source_hash()
         allrec[name] = rec
         json.dump(allrec, open(path, "w"), indent=1, sort_keys=True)
         print(json.dumps(rec, indent=1))
