@@ -755,8 +755,12 @@ static int rene_render_impl(rene_ctx* c, uint32_t first_frame, uint32_t n_frames
   // them cut into halving items down to `tail` frames; RENE_LEVELS=<n> (tests, A/B measurements) cuts into n uniform items
   {
     const uint32_t F = P.n_frames;
-    uint32_t item = c->item_frames ? c->item_frames : ((c->cfg.features & rene::FEAT_SMALL) ? 64u : 32u);
-    uint32_t tail = (c->cfg.features & rene::FEAT_SMALL) ? 8u : 4u;
+    // untuned: two dozen items per pixel and launch, at least 16 frames each (measured, one launch per job, MI355X: Cornell 1024
+    // frames flat from 48 to 96 frames per item, veach-mis 4096 frames best at 128 - 256, dragon-class 1024 at 32 - 64, the teapot
+    // scene 8192 at 256: it is the number of item switches per pixel that a launch pays for, and the length of its last item);
+    // no halving tail by default (tail = item): it buys nothing once the hand-off waits are rare
+    uint32_t item = c->item_frames ? c->item_frames : std::max(16u, F / 24u);
+    uint32_t tail = item;
     if (const char* e = std::getenv("RENE_ITEM_FRAMES")) item = (uint32_t)std::max(1, std::atoi(e));  // tuning knobs
     if (const char* e = std::getenv("RENE_ITEM_TAIL")) tail = (uint32_t)std::max(1, std::atoi(e));
     if (const char* e = std::getenv("RENE_LEVELS")) {
@@ -844,7 +848,11 @@ static int rene_render_impl(rene_ctx* c, uint32_t first_frame, uint32_t n_frames
   uint32_t blocks_needed = (total_items + rene::render_block_size() - 1) / rene::render_block_size();
   cfg.grid = std::max(1u, std::min(cfg.grid, blocks_needed));
   const uint32_t waves = cfg.grid * (uint32_t)(rene::render_block_size() / 64);
-  P.work_batch = 128;
+  // 64 ids = one wave's worth: every id a wave takes is rendered at once.  (With 128 the second half of a batch sat reserved
+  // until lanes of that wave came free, its pixels started late, and the items that continue from them -- handed out one sweep
+  // of the image later -- found them unfinished: Cornell 52.1 -> 48.5 ms per job)
+  P.work_batch = 64;
+  if (const char* e = std::getenv("RENE_WORK_BATCH")) P.work_batch = (uint32_t)std::max(16, std::min(1024, std::atoi(e)));  // tuning knob
   while (P.work_batch > 16 && (uint64_t)P.work_batch * waves * 2u > total_items) P.work_batch >>= 1;
   hipEventRecord(pend.start, stream);
   rene::g_launched_blocks = cfg.grid;
@@ -908,9 +916,9 @@ int rene_tune(rene_ctx* c, uint32_t n_frames) {
   const uint32_t saved = c->item_frames;
   uint32_t best = saved;
   double best_ms = 0.0;
-  // candidates: one item per pixel and launch, then items of 128 / 64 / 32 / 16 frames (their last ones halving, rene_render)
-  const uint32_t items[5] = {rene_ctx::kWholeLaunch, 128u, 64u, 32u, 16u};
-  for (int i = 0; i < 5; ++i) {
+  // candidates: one item per pixel and launch, then items of 256 / 128 / 64 / 32 / 16 frames
+  const uint32_t items[6] = {rene_ctx::kWholeLaunch, 256u, 128u, 64u, 32u, 16u};
+  for (int i = 0; i < 6; ++i) {
     if (i > 0 && items[i] * 2u > n_frames) continue;
     c->item_frames = items[i];
     const auto t0 = std::chrono::steady_clock::now();
@@ -979,11 +987,15 @@ int rene_get_stats(rene_ctx* c, rene_stats* out) {
   if (rc != RENE_OK) return rc;
   unsigned long long h[24];
   HIP_TRY(hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
-  if (std::getenv("RENE_DEBUG") && h[12])  // RENE_FLAG_COUNTERS on the traversal-restart kernel: lanes active per step kind
+  if (std::getenv("RENE_DEBUG") && h[23])  // RENE_FLAG_COUNTERS on the megakernels of device_code.inc: where the lanes of a pass were
+    std::fprintf(stderr, "[rene] passes %llu (wave executions of the loop); lanes per pass: on a path %.3f, waiting for a hand-off %.3f, out of work %.3f, starting a path %.3f; "
+                         "passes with an item switch %.4f, with a poll %.4f\n", h[12], (double)h[13] / (64.0 * (double)h[12]), (double)h[14] / (64.0 * (double)h[12]),
+                 (double)h[15] / (64.0 * (double)h[12]), (double)h[16] / (64.0 * (double)h[12]), (double)h[17] / (double)h[12], (double)h[18] / (double)h[12]);
+  else if (std::getenv("RENE_DEBUG") && h[12])  // RENE_FLAG_COUNTERS on the traversal-restart kernel: lanes active per step kind
     std::fprintf(stderr, "[rene] steps (wave executions, lanes, lanes / 64 per execution): node %llu %llu %.3f | leaf %llu %llu %.3f | logic %llu %llu %.3f | iterations %llu\n",
                  h[12], h[6], (double)h[6] / (64.0 * (double)h[12]), h[13], h[16], (double)h[16] / (64.0 * (double)std::max(1ull, h[13])), h[14], h[15],
                  (double)h[15] / (64.0 * (double)std::max(1ull, h[14])), h[17]);
-  if (std::getenv("RENE_DEBUG") && h[12])
+  if (std::getenv("RENE_DEBUG") && h[12] && !h[23])
     std::fprintf(stderr, "[rene] node visits %llu: nothing hit %llu (%.3f), reached by a pop %llu (%.3f), both %llu (%.3f); in the top levels %llu (%.3f); deepest stack %llu entries\n", h[6], h[18],
                  (double)h[18] / (double)h[6], h[19], (double)h[19] / (double)h[6], h[20], (double)h[20] / (double)h[6], h[22], (double)h[22] / (double)h[6], h[21]);
   std::memset(out, 0, sizeof(*out));

@@ -404,3 +404,25 @@ def teapot_full(xres: int = 1920, yres: int = 1080, asset_dir: str | None = None
         return loader.load_pbrt(os.path.join(tmp, "scene.pbrt"))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def dragon_partial(xres: int = 1280, yres: int = 720, asset_dir: str | None = None):
+    """rene's sample_scenes/dragon with the 12 of its 16 meshes the checkout holds (tests/golden/dragon_partial: 'Dragon' by
+    Delatronic, CC-BY 3.0; the body and two ground pieces are missing upstream), through the pbrt-v3 loader, Film size replaced:
+    real artist meshes as a BVH datapoint next to the procedural dragon-class stand-in.  Returns a rene_amd.loader.LoadedScene."""
+    import os
+    import re
+    import shutil
+    import tempfile
+    from . import loader
+    src = asset_dir or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "dragon_partial")
+    tmp = tempfile.mkdtemp(prefix="rene_dragon_")
+    try:
+        text = open(os.path.join(src, "scene.pbrt")).read()
+        text = re.sub(r'"integer xresolution" \[ \d+ \]', f'"integer xresolution" [ {xres} ]', text)
+        text = re.sub(r'"integer yresolution" \[ \d+ \]', f'"integer yresolution" [ {yres} ]', text)
+        open(os.path.join(tmp, "scene.pbrt"), "w").write(text)
+        os.symlink(os.path.join(src, "models"), os.path.join(tmp, "models"))
+        return loader.load_pbrt(os.path.join(tmp, "scene.pbrt"))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)

@@ -34,7 +34,7 @@ def test_t2_cornell_vs_renes_render():
     want = np.load(os.path.join(GOLDEN, "rene_cornell_box8.npy"))
     rmse = float(np.sqrt(((got - want) ** 2).mean()))
     print("T2 Cornell sRGB RMSE vs rene:", rmse)
-    assert rmse < 0.009  # measured 0.0057; rene vs Tungsten: 0.043
+    assert rmse < 0.0072  # measured 0.00575 (x 1.25); rene vs Tungsten: 0.043
 
 
 def test_t2_veach_mis_vs_renes_render():
@@ -43,4 +43,81 @@ def test_t2_veach_mis_vs_renes_render():
     rmse = float(np.sqrt(((got - want) ** 2).mean()))
     ratio = float(got.mean() / want.mean())
     print("T2 veach-mis sRGB RMSE vs rene:", rmse, "mean ratio", ratio)
-    assert rmse < 0.012 and abs(ratio - 1) < 0.03  # measured 0.0067; rene vs Tungsten: 0.174
+    assert rmse < 0.009 and abs(ratio - 1) < 0.012  # measured 0.00716 (x 1.25) / 0.9919; rene vs Tungsten: 0.174
+
+
+# ---- rene's own sample count, 4 x 4 boxes, and the energy of every surface -----------------------------
+def _t2_regions(name, scene, oracle_mod, spp=5000):
+    import t2_regions as T
+    srgb4, lin4 = T.rene_box4(name)
+    with api.Renderer(scene) as r:
+        r.render(0, spp)
+        rgb8 = api.to_rgb8(r.download(0), spp)
+    mine4 = T.box(rgb8.astype(np.float32) / 255.0, 4)
+    rmse = float(np.sqrt(((mine4 - srgb4) ** 2).mean()))
+    reg = T.region_map(oracle_mod, scene, 4)
+    mine_lin4 = T.box(T.to_linear(rgb8.astype(np.float32) / 255.0), 4)
+    rows = []
+    for rid in np.unique(reg):
+        m = reg == rid
+        if rid < 0 or m.sum() < 150:
+            continue
+        a, b = mine_lin4[m].mean(axis=0), lin4[m].mean(axis=0)
+        rows.append((int(rid) >> 12, int(rid) & 4095, int(m.sum()), b, a / np.maximum(b, 1e-9)))
+    return rmse, rows
+
+
+def _show(rows):
+    return "\n".join(f"  instance {i} quad {q}: {c} cells, rene linear {np.round(b, 4)}, ratio {np.round(r, 4)}" for i, q, c, b, r in rows)
+
+
+# Measured on the MI355X in round 3 (5000 frames, fixed seed schedule: reproducible): mean linear radiance of the region here /
+# in rene's PNG, per channel, for the channels rene's 8 bits resolve (mean linear in [0.03, 0.9): a quantisation step is then
+# below 3 % and the image's own noise dithers it).  (instance, quad) -> ratios.  The build is 1 - 4 % brighter than rene's
+# published Cornell on the walls and the floor and 6.4 % on the ceiling (instance 1; there the ratio also varies over the
+# surface, 0.95 near the light to 1.06 away from it) -- offsets of the published image, whose code version is unknown (the
+# checkout has no history); the ORACLE shows the same offsets (tests/test_oracle_render.py), so they are not the HIP path's.
+# The test pins every ratio to +- 1 %: a one-per-cent change of the energy of any one surface fails it.
+T2_CORNELL_RATIOS = {
+    (0, 0): (1.0205, 1.0169, None), (1, 0): (1.0638, 1.0647, None), (2, 0): (1.0326, 1.0315, 1.0266),
+    (3, 0): (1.0284, 1.0276, None), (4, 0): (1.0373, None, None), (5, 1): (None, 1.0135, None),
+    (6, 1): (1.0194, 1.0157, None), (6, 4): (0.9888, None, None),
+}
+T2_VEACH_RATIOS = {
+    (0, 1): (0.9978, 0.9979, 0.9979), (0, 5): (1.0279, None, None), (1, 1): (0.9949, 0.9948, 0.9948), (1, 5): (1.0154, None, None),
+    (2, 1): (0.9934, 0.9925, 0.9925), (2, 5): (1.0201, None, None), (3, 0): (0.9849, 0.9825, 0.9817), (4, 0): (0.9819, 0.9811, 0.9809),
+    (8, 1): (0.9781, 0.9733, 0.9728),
+}
+T2_CORNELL_BOX4_RMSE = 0.0070  # measured 0.00565 (x 1.24); 8 x 8 boxes at 2048 spp: 0.0057
+T2_VEACH_BOX4_RMSE = 0.0114    # measured 0.00919 (x 1.24)
+
+
+def _check_regions(rows, expected):
+    checked = 0
+    for i, q, c, b, r in rows:
+        for ch in range(3):
+            if 0.03 <= b[ch] < 0.9:
+                want = expected.get((i, q), (None, None, None))[ch]
+                assert want is not None, f"region ({i}, {q}) channel {ch} (rene {b[ch]:.4f}, ratio {r[ch]:.4f}) has no recorded ratio"
+                assert abs(r[ch] - want) < 0.01, (i, q, ch, float(r[ch]), want)
+                checked += 1
+    return checked
+
+
+def test_t2_cornell_at_renes_5000_spp_box4_and_every_surface(oracle_mod):
+    """rene's Cornell at rene's own sample count against rene's PNG: 4 x 4 box sRGB RMSE, and the mean linear radiance of every
+    surface the camera sees (walls, floor, ceiling, the visible faces of both blocks; tests/t2_regions.py)."""
+    rmse, rows = _t2_regions("cornell", scenes.cornell_box(1024, 1024), oracle_mod)
+    print("T2 Cornell 5000 spp, 4 x 4 box sRGB RMSE vs rene:", rmse)
+    print(_show(rows))
+    assert rmse < T2_CORNELL_BOX4_RMSE
+    assert _check_regions(rows, T2_CORNELL_RATIOS) >= 14
+
+
+def test_t2_veach_mis_at_renes_5000_spp_box4_and_every_surface(oracle_mod):
+    """The same for veach-mis (Metal plates, sphere emitters): every plate, the floor, the wall."""
+    rmse, rows = _t2_regions("veach_mis", scenes.veach_mis(1280, 720), oracle_mod)
+    print("T2 veach-mis 5000 spp, 4 x 4 box sRGB RMSE vs rene:", rmse)
+    print(_show(rows))
+    assert rmse < T2_VEACH_BOX4_RMSE
+    assert _check_regions(rows, T2_VEACH_RATIOS) >= 20

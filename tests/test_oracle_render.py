@@ -114,7 +114,7 @@ def test_t2_against_renes_published_cornell(oracle_mod):
     tung = tung.reshape(n, k, n, k, 3).mean(axis=(1, 3))
     rmse_t = float(np.sqrt(((box(mine) - box(tung)) ** 2).mean()))
     print("T2 sRGB RMSE vs rene:", rmse, " vs Tungsten:", rmse_t)
-    assert rmse < 0.02
+    assert rmse < 0.0188  # measured 0.0150 (x 1.25)
     assert rmse < rmse_t  # closer to rene than to the unbiased answer
 
 
@@ -137,7 +137,7 @@ def test_t2_veach_mis_against_renes_published_render(oracle_mod):
     rmse = float(np.sqrt(((box(mine) - box(want)) ** 2).mean()))
     ratio = float(mine.mean() / want.mean())
     print("oracle T2 veach-mis sRGB RMSE vs rene:", rmse, "mean ratio", ratio)
-    assert rmse < 0.025 and abs(ratio - 1) < 0.03  # measured 0.0156 / 0.991; rene vs the unbiased Tungsten image: 0.174
+    assert rmse < 0.0195 and abs(ratio - 1) < 0.012  # measured 0.0156 (x 1.25) / 0.991; rene vs the unbiased Tungsten image: 0.174
 
 
 def test_t2_cornell_against_renes_published_render_from_the_fixture(oracle_mod):
@@ -151,4 +151,36 @@ def test_t2_cornell_against_renes_published_render_from_the_fixture(oracle_mod):
     box = lambda x: x.reshape(16, 8, 16, 8, 3).mean(axis=(1, 3))
     rmse = float(np.sqrt(((box(mine) - box(want)) ** 2).mean()))
     print("oracle T2 Cornell sRGB RMSE vs rene (fixture):", rmse)
-    assert rmse < 0.02
+    assert rmse < 0.0188  # measured 0.0150 (x 1.25)
+
+
+def test_t2_cornell_energy_of_every_surface_against_renes_render(oracle_mod):
+    """an 8 x 8 box RMSE lets a one-per-cent energy error in one wall through.  Here every surface the camera
+    sees (tests/t2_regions.py: cut by the oracle's own first hits) is compared in mean linear radiance with rene's PNG, in the
+    channels its 8 bits resolve.  4096 frames: rene's frame-wide generator (Q3) gives all pixels of a frame the same light /
+    BSDF coin and the same point on the light, so a region's mean converges with the number of FRAMES, not of pixels.
+    Measured (round 3): the oracle is 1.6 - 2.9 % brighter than rene's image on the walls, the floor, the ceiling and the tall
+    block, 0.4 - 0.9 % darker on the right wall -- a systematic offset of the published image (whose code version is not
+    known: the checkout has no history) that no depth cap reproduces (cap 8: +0.4 ... +1.7 %; cap 6: -3.5 ... +0.9 %).  The
+    bound is 1.25 x the largest measured deviation."""
+    import t2_regions as T
+    spp = 4096
+    reg = T.region_map(oracle_mod, scenes.cornell_box(1024, 1024), 8)
+    _, lin4 = T.rene_box4("cornell")
+    lin8 = T.box(lin4, 2)
+    o = oracle_mod.Oracle(scenes.cornell_box(128, 128))
+    o.render(0, spp)
+    mine = T.to_linear(oracle_mod.to_rgb8(o.download(0), spp).astype(np.float32) / 255.0)
+    checked, worst = 0, 0.0
+    for rid in np.unique(reg):
+        m = reg == rid
+        if rid < 0 or m.sum() < 300:  # (smaller regions are all edge at this resolution; the GPU test has them at 4 x 4)
+            continue
+        a, b = mine[m].mean(axis=0), lin8[m].mean(axis=0)
+        for ch in range(3):
+            if 0.03 <= b[ch] < 0.9:
+                checked += 1
+                worst = max(worst, abs(float(a[ch] / b[ch]) - 1.0))
+                assert abs(a[ch] / b[ch] - 1.0) < 0.037, (int(rid) >> 12, int(rid) & 4095, ch, float(a[ch] / b[ch]))
+    print("oracle vs rene, region energies: largest deviation", worst, "over", checked, "region-channels")
+    assert checked >= 10
