@@ -30,7 +30,7 @@ The JSON line also carries
                   counts per ray come from the committed rocprofv3 PMC passes (profiles/pmc_per_ray.json:
                   per RAY, so they hold whatever K is; `pmc_stale` says whether the kernel sources have changed since
                   those passes); rates are measured live.  `useful_lane_frac` = frac x lanes active; `sclk_mhz` = the
-                  engine clock sampled during the timed jobs.  `hbm` inside it = the measured
+                  engine clock during the last timed job, measured by the kernel itself (rene_stats.sclk_mhz).  `hbm` inside it = the measured
                   HBM bytes per ray (FETCH_SIZE x 2 + WRITE_SIZE, same passes) x live rays/s against 8 TB/s, and
                   SURVEY 8d's cache-less algorithmic bytes for comparison (not a fraction of anything: the scene
                   lives in the caches).  `traffic` = measured HBM bytes per launch.
@@ -90,47 +90,6 @@ def kernel_source_hash() -> str:
         if line.startswith("HIPFLAGS"):
             h.update(line.encode())
     return h.hexdigest()[:16]
-
-
-class ClockSampler:
-    """Samples the GPU's engine clock (sysfs pp_dpm_sclk, the entry marked '*') from a thread while the timed jobs run."""
-
-    def __init__(self, device: int):
-        import glob
-        self.paths = sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"))
-        self.path = self.paths[min(device, len(self.paths) - 1)] if self.paths else None
-        self.samples, self._stop, self._t = [], False, None
-
-    def _read(self):
-        try:
-            for line in open(self.path):
-                if "*" in line:
-                    return float(line.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
-        except Exception:
-            return None
-        return None
-
-    def _run(self):
-        while not self._stop:
-            v = self._read()
-            if v:
-                self.samples.append(v)
-            time.sleep(0.02)
-
-    def __enter__(self):
-        if self.path:
-            import threading
-            self._t = threading.Thread(target=self._run, daemon=True)
-            self._t.start()
-        return self
-
-    def __exit__(self, *a):
-        self._stop = True
-        if self._t:
-            self._t.join(timeout=1.0)
-
-    def median(self):
-        return statistics.median(self.samples) if self.samples else None
 
 
 def pmc_per_ray(name: str):
@@ -355,18 +314,17 @@ def main():
     step_ms, first_image, identical = [], None, True
     kernel_ms, n_launches, rays_job = 0.0, 0, 0
     fence()
-    with ClockSampler(local) as clock:
-        t0 = time.perf_counter()
-        for k in range(K):
-            t1 = time.perf_counter()
-            job()
-            step_ms.append((time.perf_counter() - t1) * 1e3)
-            if k == 0 or k == K - 1:  # bookkeeping of the first and last job only: a few host-side reads, no device work
-                st = r.stats()
-                kernel_ms, n_launches, rays_job = st.kernel_ms, st.launches, st.rays
-        fence()
-        elapsed = time.perf_counter() - t0
-    sclk = clock.median()
+    sclk = None
+    t0 = time.perf_counter()
+    for k in range(K):
+        t1 = time.perf_counter()
+        job()
+        step_ms.append((time.perf_counter() - t1) * 1e3)
+        if k == 0 or k == K - 1:  # bookkeeping of the first and last job only: a few host-side reads, no device work
+            st = r.stats()
+            kernel_ms, n_launches, rays_job, sclk = st.kernel_ms, st.launches, st.rays, st.sclk_mhz
+    fence()
+    elapsed = time.perf_counter() - t0
 
     # every job renders the same frames: the last image equals a fresh render of the job, bit for bit (one GPU; with
     # N > 1 the exchange changes rank 0's image in place, compared there as well: the reduce is deterministic)
@@ -423,7 +381,7 @@ def main():
                          "valu": rl["valu"], "hbm": rl["hbm"],
                          "note": "the scene is cache resident: VALU issue is the roof that binds, priced at 2 cycles per wave64 "
                                  "VALU instruction on a SIMD-32 (transcendentals 4), nominal 2.4 GHz (`sclk_mhz`: what the clock was "
-                                 "during the timed jobs); rates are the sustained ones (rays of the timed jobs / elapsed); `launch_ms` = "
+                                 "during the last timed job, measured by the kernel); rates are the sustained ones (rays of the timed jobs / elapsed); `launch_ms` = "
                                  "HIP events around the launch, on its stream (what rocprofv3 reports per dispatch); `useful_lane_frac` = "
                                  "frac x lanes active; `pmc_stale`: the kernel sources differ from the ones the PMC passes ran on; "
                                  "`hbm.frac` is measured HBM traffic (PMC) against 8 TB/s"},

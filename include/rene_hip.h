@@ -238,6 +238,8 @@ typedef struct rene_stats {
   uint64_t launches;      /* kernel launches so far (a launch that had to be replayed after dropped work items counts again) */
   double kernel_ms;       /* sum of HIP-event durations of those launches */
   double last_launch_ms;
+  double sclk_mhz;        /* engine clock while those launches ran, measured by the kernels (shader-clock ticks per tick of the
+                             constant 100 MHz clock over the lifetime of one wave per launch); 0 before the first launch (ABI v4) */
 } rene_stats;
 
 /* One closest-hit record (what Vulkan traversal hands the hit shaders: t, instance, primitive,

@@ -107,7 +107,7 @@ class Stats(C.Structure):
     _fields_ = [("rays_closest", u64), ("rays_shadow", u64), ("rays_emitter", u64),
                 ("paths", u64), ("bounces", u64), ("hits", u64), ("adds", u64),
                 ("node_visits", u64), ("prim_tests", u64), ("frames", u64), ("launches", u64),
-                ("kernel_ms", C.c_double), ("last_launch_ms", C.c_double)]
+                ("kernel_ms", C.c_double), ("last_launch_ms", C.c_double), ("sclk_mhz", C.c_double)]
 
     @property
     def rays(self) -> int:

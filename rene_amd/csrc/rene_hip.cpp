@@ -554,6 +554,7 @@ static int rene_create_impl(const rene_scene_desc* scene, const rene_opts* opts,
   uint32_t stack = 16;
   while (stack < depth) stack += 4;  // 40 entries x 1024 lanes x 4 B = the whole 160 KB of a CU at 4 waves per SIMD
   if (stack > 96) return fail(RENE_ERR_UNSUPPORTED, "BVH deeper than the 96-entry traversal stack");
+  if (const char* e = std::getenv("RENE_STACK_ENTRIES")) stack = (uint32_t)std::max(8, std::atoi(e));  // occupancy EXPERIMENTS only: unchecked
   c->cfg.features = ps.features;
   if (o.flags & RENE_FLAG_FORCE_BVH) c->cfg.features &= ~rene::FEAT_SMALL;
   c->cfg.stack_depth = stack;
@@ -629,11 +630,11 @@ static int rene_create_impl(const rene_scene_desc* scene, const rene_opts* opts,
   }
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_work_counters), rene_ctx::kCounters * sizeof(uint32_t)));
   HIP_TRY(hipMemsetAsync(c->d_work_counters, 0, rene_ctx::kCounters * sizeof(uint32_t), c->stream));
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_counters), 24 * sizeof(unsigned long long)));
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_counters), 32 * sizeof(unsigned long long)));
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_item_done), std::max<size_t>(1, c->n_work) * sizeof(uint32_t)));
   HIP_TRY(hipMemsetAsync(c->d_item_done, 0, std::max<size_t>(1, c->n_work) * sizeof(uint32_t), c->stream));
   HIP_TRY(hipMemsetAsync(c->fb, 0, c->fb_floats * sizeof(float), c->stream));  // main.rs:1229-1237
-  HIP_TRY(hipMemsetAsync(c->d_counters, 0, 24 * sizeof(unsigned long long), c->stream));
+  HIP_TRY(hipMemsetAsync(c->d_counters, 0, 32 * sizeof(unsigned long long), c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   HIP_TRY(hipDeviceSynchronize());  // everything the uploads left on the null stream (the fills of empty tables) has run: see zero_now
 
@@ -755,11 +756,12 @@ static int rene_render_impl(rene_ctx* c, uint32_t first_frame, uint32_t n_frames
   // them cut into halving items down to `tail` frames; RENE_LEVELS=<n> (tests, A/B measurements) cuts into n uniform items
   {
     const uint32_t F = P.n_frames;
-    // untuned: two dozen items per pixel and launch, at least 16 frames each (measured, one launch per job, MI355X: Cornell 1024
-    // frames flat from 48 to 96 frames per item, veach-mis 4096 frames best at 128 - 256, dragon-class 1024 at 32 - 64, the teapot
-    // scene 8192 at 256: it is the number of item switches per pixel that a launch pays for, and the length of its last item);
+    // untuned: a dozen items per pixel and launch for the item-loop kernels, 32 for the BVH kernels, at least 16 frames each
+    // (measured, one launch per job, MI355X: Cornell 1024 frames flat from 64 to 96 frames per item, veach-mis 4096 frames best at
+    // 256 - 341, dragon-class 1024 at 32, the teapot scene 8192 at 256: it is the number of item switches per pixel that a launch
+    // pays for, and the length of its last item -- and a BVH scene's pixels differ more in cost);
     // no halving tail by default (tail = item): it buys nothing once the hand-off waits are rare
-    uint32_t item = c->item_frames ? c->item_frames : std::max(16u, F / 24u);
+    uint32_t item = c->item_frames ? c->item_frames : std::max(16u, F / ((c->cfg.features & rene::FEAT_SMALL) ? 12u : 32u));
     uint32_t tail = item;
     if (const char* e = std::getenv("RENE_ITEM_FRAMES")) item = (uint32_t)std::max(1, std::atoi(e));  // tuning knobs
     if (const char* e = std::getenv("RENE_ITEM_TAIL")) tail = (uint32_t)std::max(1, std::atoi(e));
@@ -894,7 +896,7 @@ int rene_reset(rene_ctx* c) {
   c->handoff_failed = false;  // the counters are cleared below and the image starts again from zero
   c->exchanged = false;
   HIP_TRY(hipMemsetAsync(c->fb, 0, c->fb_floats * sizeof(float), c->stream));
-  HIP_TRY(hipMemsetAsync(c->d_counters, 0, 24 * sizeof(unsigned long long), c->stream));
+  HIP_TRY(hipMemsetAsync(c->d_counters, 0, 32 * sizeof(unsigned long long), c->stream));
   HIP_TRY(hipMemsetAsync(c->d_item_done, 0, std::max<size_t>(1, c->n_work) * sizeof(uint32_t), c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->prev_final = 0;  // the pixel records carry version 0 again
@@ -985,7 +987,7 @@ int rene_get_stats(rene_ctx* c, rene_stats* out) {
   HIP_TRY(hipSetDevice(c->device));
   int rc = c->drain();
   if (rc != RENE_OK) return rc;
-  unsigned long long h[24];
+  unsigned long long h[32];
   HIP_TRY(hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
   if (std::getenv("RENE_DEBUG") && h[23])  // RENE_FLAG_COUNTERS on the megakernels of device_code.inc: where the lanes of a pass were
     std::fprintf(stderr, "[rene] passes %llu (wave executions of the loop); lanes per pass: on a path %.3f, waiting for a hand-off %.3f, out of work %.3f, starting a path %.3f; "
@@ -1012,6 +1014,9 @@ int rene_get_stats(rene_ctx* c, rene_stats* out) {
   out->launches = c->launches + c->replays;  // launches that had to be launched again (drain) count twice
   out->kernel_ms = c->kernel_ms;
   out->last_launch_ms = c->last_ms;
+  // the engine clock while the launches ran: shader-clock ticks (s_memtime) per tick of the constant 100 MHz clock
+  // (s_memrealtime) over the lifetime of one wave of each launch (device_code.inc, clock_probe)
+  out->sclk_mhz = h[25] ? 100.0 * (double)h[24] / (double)h[25] : 0.0;
   return RENE_OK;
 }
 

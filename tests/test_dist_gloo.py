@@ -29,7 +29,7 @@ def _gather_worker(rank, world, port, q):
     from rene_amd import abi, dist as rdist, scenes
     from oracle import oracle
     rdist.init_process_group("gloo")
-    o = oracle.Oracle(scenes.cornell_box(128, 96))  # 4 x 3 tiles, 12 % 2 == 0 and 12 % 3 == 0
+    o = oracle.Oracle(scenes.cornell_box(128, 128 if world == 8 else 96))  # 4 x 3 tiles (12 % 2 == 12 % 3 == 0); world 8: 4 x 4
     o.render(0, 2, threads=1, shard_mode=abi.SHARD_TILES, shard_rank=rank, shard_count=world)
     fb = torch.from_numpy(np.stack([o.download(l, 4) for l in range(3)]))
     rdist.gather_owned_tiles(fb, rank, world, dst=0)
@@ -39,7 +39,7 @@ def _gather_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_gather_owned_tiles_equals_single(world):
     import torch.multiprocessing as mp
     from rene_amd import scenes
@@ -54,7 +54,7 @@ def test_gather_owned_tiles_equals_single(world):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    o = oracle.Oracle(scenes.cornell_box(128, 96))
+    o = oracle.Oracle(scenes.cornell_box(128, 128 if world == 8 else 96))
     o.render(0, 2, threads=1)
     want = np.stack([o.download(l, 4) for l in range(3)])
     assert np.array_equal(got, want)
@@ -131,9 +131,10 @@ def _frame_worker(rank, world, port, q, total):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,total", [(2, 7), (3, 8)])
+@pytest.mark.parametrize("world,total", [(2, 7), (3, 8), (8, 16)])
 def test_frame_block_reduce_equals_single_up_to_summation_order(world, total):
-    """bench.py's N > 1 cut: contiguous frame blocks + one reduce of the partial images."""
+    """bench.py's N > 1 cut (strong scaling: the job's frames dealt out in contiguous blocks, 8 ranks included) + one reduce of
+    the partial images."""
     import torch.multiprocessing as mp
     from rene_amd import scenes
     from rene_amd.dist import frame_block

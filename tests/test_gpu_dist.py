@@ -23,13 +23,13 @@ def _worker(rank, world, port, q, cut):
     rdist.init_process_group("gloo")
     s = scenes.cornell_box(160, 96)  # ragged against the 32x32 tiles: 5 x 3 tiles over 2 ranks
     fb = torch.zeros((3, 96, 160, 4), dtype=torch.float32, device="cuda:0")
-    frames = 9
+    frames = 10
     if cut == "tiles":
-        r = api.Renderer(s, device=0, flags=abi.FLAG_OVERLAP, shard_mode=abi.SHARD_TILES, shard_rank=rank, shard_count=world, framebuffer_ptr=fb.data_ptr())
+        r = api.Renderer(s, device=0, shard_mode=abi.SHARD_TILES, shard_rank=rank, shard_count=world, framebuffer_ptr=fb.data_ptr())
         for f0 in range(0, frames, 4):
             r.render(f0, min(4, frames - f0))
     else:
-        r = api.Renderer(s, device=0, flags=abi.FLAG_OVERLAP, framebuffer_ptr=fb.data_ptr())
+        r = api.Renderer(s, device=0, framebuffer_ptr=fb.data_ptr())
         lo, hi = rdist.frame_block(rank, world, frames)
         for f0 in range(lo, hi, 2):
             r.render(f0, min(2, hi - f0))
@@ -46,14 +46,16 @@ def _worker(rank, world, port, q, cut):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("cut", ["tiles", "frames"])
-def test_two_ranks_on_the_hip_path_equal_one(cut):
+@pytest.mark.parametrize("cut,world", [("tiles", 2), ("frames", 2), ("tiles", 4), ("frames", 4)])
+def test_ranks_on_the_hip_path_equal_one(cut, world):
+    """world 2 and 4 (a GPU box admits six processes on its card; world 8 is rehearsed on the CPU, test_dist_gloo.py): the
+    strong-scaling job of bench.py --gpus N -- the SAME image and sample count whatever N -- cut by tiles or by frame blocks."""
     import torch.multiprocessing as mp
     from rene_amd import api, scenes
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, cut)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, cut)) for r in range(world)]
     for p in procs:
         p.start()
     got = q.get(timeout=300)
@@ -61,7 +63,7 @@ def test_two_ranks_on_the_hip_path_equal_one(cut):
         p.join(timeout=60)
         assert p.exitcode == 0
     with api.Renderer(scenes.cornell_box(160, 96)) as r:
-        r.render(0, 9)
+        r.render(0, 10)
         want = np.stack([r.download(l) for l in range(3)])
     if cut == "tiles":
         assert np.array_equal(got, want)  # every pixel has one owner

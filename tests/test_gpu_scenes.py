@@ -270,14 +270,14 @@ def test_dragon_partial_real_meshes_against_the_oracle(oracle_mod):
     sg, so = _compare(s, 8, oracle_mod, frac=5e-3, relmse=1e-3, ctol=2e-3)
     assert sg["rays_shadow"] > 0 and sg["rays_emitter"] == 0
     o = oracle_mod.Oracle(s)
-    rng = np.random.default_rng(11)
-    rays = [o.camera_ray(float(u), float(v)) for u, v in rng.uniform(0.02, 0.98, size=(6000, 2))]
+    rng = np.random.default_rng(11)  # (a tenth of the film sees geometry: the ground and the dragon's body are among the missing meshes)
+    rays = [o.camera_ray(float(u), float(v)) for u, v in rng.uniform(0.02, 0.98, size=(12000, 2))]
     org, d = np.stack([r[0] for r in rays]).astype(np.float32), np.stack([r[1] for r in rays]).astype(np.float32)
     with api.Renderer(s) as r:
         hg, ho = r.trace(org, d), o.trace(org, d)
     tie = np.abs(hg["t"] - ho["t"]) <= 2e-5 * (1 + np.abs(ho["t"]))
     bad = ((hg["t"] < 0) != (ho["t"] < 0)) | ((ho["t"] >= 0) & ((hg["primitive"] != ho["primitive"]) | (hg["instance"] != ho["instance"])) & ~tie)
-    assert (ho["t"] > 0).sum() > 1000 and bad.sum() <= 3, bad.sum()
+    assert (ho["t"] > 0).sum() > 800 and bad.sum() <= 3, bad.sum()
 
 
 @pytest.mark.parametrize("name", ["dragon-class", "teapot-full"])
@@ -379,3 +379,28 @@ def test_instance_and_light_tables_in_lds_are_bit_identical(monkeypatch, name):
             images.append([r.download(l) for l in range(3)])
     for a, b in zip(*images):
         assert np.array_equal(a, b)
+
+
+def test_soak_many_launches_none_replayed():
+    """rounds 1-2 overlapped consecutive launches on two streams and now and then a launch stalled for
+    seconds behind the next one's waiters; launches are serial now and no launch waits for another.
+    Thirty jobs of sixteen launches each at full size on rene's teapot scene: every launch issued is a launch counted --
+    none dropped a work item and had to be launched again -- and every job's image equals the first one's, bit for bit."""
+    s = scenes.teapot_full(1920, 1080)
+    jobs, per_job, frames = 30, 16, 24
+    first = None
+    with api.Renderer(s) as r:
+        for j in range(jobs):
+            r.reset()
+            for k in range(per_job):
+                r.render(k * frames, frames)
+            r.sync()
+            st = r.stats().as_dict()
+            assert st["launches"] == per_job, (j, st["launches"])  # a replayed launch would count again
+            if j in (0, jobs // 2, jobs - 1):
+                img = r.download(0)
+                if first is None:
+                    first = img
+                else:
+                    assert np.array_equal(img, first), j
+    assert np.isfinite(first).all() and first.sum() > 0
