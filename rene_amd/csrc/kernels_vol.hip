@@ -1,5 +1,6 @@
 // kernels_vol.hip -- render kernels of the volumetric integrator (Integrator "volpath", lib.rs:477-803):
-// render_kernel with FEAT_VOLPATH, over the item loop (small scenes) or the while-while BVH traversal.
+// render_kernel with FEAT_VOLPATH over the item loop (small scenes) or the while-while BVH traversal (shallow trees), and
+// render_kernel_wf with FEAT_VOLPATH (deep trees: traversal restart).
 // Separate translation unit so that it compiles in parallel with the path-integrator families.
 #include "device_code.inc"  // opens namespace rene
 
@@ -11,9 +12,19 @@ static hipError_t launch_vol(const LaunchConfig& cfg, const SceneView& S, const 
   bool count = (P0.flags & RENE_FLAG_COUNTERS) != 0, aov = !(P0.flags & RENE_FLAG_NO_AOV);
   RenderParams P = P0;
   auto kernel = (count || aov) ? render_kernel<FEAT, MAXL, true, true> : render_kernel<FEAT, MAXL, false, false>;
+  // deep trees: the traversal-restart scheduling of render_wf.inc, its walks (tr / tr_emit) as phases of the state machine
+  // (shallow ones -- a few hundred nodes -- stay with the while-while loop, as in kernels_bvh.hip); RENE_FLAG_NO_RESTART: A/B tests
+  if constexpr (!(FEAT & FEAT_SMALL)) {
+    if (!(P.flags & RENE_FLAG_NO_RESTART) && S.main.n_nodes > 512u) {
+      kernel = count ? render_kernel_wf<FEAT, MAXL, true, true, false> : (aov ? render_kernel_wf<FEAT, MAXL, false, true, false> : render_kernel_wf<FEAT, MAXL, false, false, false>);
+      P.stack_entries = cfg.stack_depth;
+    }
+  }
   seed_tables_place(P, lds);
   fit_grid(kernel, lds, cfg, P, grid);
-  hipLaunchKernelGGL(kernel, grid, block, lds, st, S, P);
+  SceneView V = S;
+  V.lds_insts = 0;
+  hipLaunchKernelGGL(kernel, grid, block, lds, st, V, P);
   return hipGetLastError();
 }
 

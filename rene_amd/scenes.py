@@ -326,6 +326,23 @@ def dragon_class(xres: int = 1920, yres: int = 1080, n_lat: int = 640, n_lon: in
     return s
 
 
+def dragon_fog(xres: int = 1920, yres: int = 1080, n_lat: int = 640, n_lon: int = 680, emitter: bool = True) -> Scene:
+    """The dragon-class room under Integrator "volpath" (SURVEY 8 f1 on a BVH-sized scene): a thin forward-scattering fog fills
+    the room, the displaced sphere stands in it, the distant light reaches every vertex through the fog's boundary (tr walks,
+    lib.rs:359-409); with `emitter` a dim quad light hangs under where the ceiling would be, so that scattering vertices and
+    surfaces also draw their emitter sample (tr_emit, the one-sample mixture)."""
+    s = dragon_class(xres, yres, n_lat, n_lon)
+    s.integrator = abi.INTEGRATOR_VOLPATH
+    s.film.filename = "dragon-fog.png"
+    fog = s.add_medium_homogeneous((0.01, 0.01, 0.015), (0.22, 0.22, 0.24), 0.35)
+    s.add_triangle_mesh(_aabb((-0.995, 0.005, -0.995), (0.995, 1.95, 0.995)), 0, interior=fog, exterior=0)
+    if emitter:
+        light = s.add_area_light_diffuse((8.5, 6.0, 2.0))
+        s.add_triangle_mesh(_quad([-0.24, 1.9, -0.22, 0.23, 1.9, -0.22, 0.23, 1.9, 0.16, -0.24, 1.9, 0.16], (0, -1, 0)),
+                            s.add_matte((0.0, 0.0, 0.0)), area_light=light, interior=fog, exterior=fog)
+    return s
+
+
 # ---------------------------------------------------------------------------------------------------
 # teapot-class (BASELINE config 5): sample_scenes/teapot/scene.pbrt is 126 048 triangles of Substrate
 # (Ks 0.04, roughness 0.001, remaproughness false) on a Matte floor with a 20 x 20 checkerboard under an

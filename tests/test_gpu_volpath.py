@@ -129,3 +129,52 @@ def test_full_size_fog_is_consistent_with_the_oracle_checked_size():
     q = [25, 50, 75, 90]  # 4096 pixels each: the upper quantiles are stable to ~2 %, the lower to ~8 %
     np.testing.assert_allclose(np.percentile(lum(img[8::16, 8::16]), q), np.percentile(lum(ref), q), rtol=0.1)
     np.testing.assert_allclose(np.percentile(lum(img[8::16, 8::16]), q[1:]), np.percentile(lum(ref), q[1:]), rtol=0.05)
+
+
+# ---- volpath on deep trees: the traversal-restart scheduling (render_wf.inc, FEAT_VOLPATH) ----------------
+@pytest.mark.parametrize("emitter", [True, False])
+def test_volpath_restart_kernel_equals_the_while_while_kernel_bit_for_bit(emitter):
+    """A tree of more than 512 nodes renders through render_kernel_wf with the walks (tr / tr_emit) as phases of its state machine;
+    RENE_FLAG_NO_RESTART keeps the while-while loop.  Same arithmetic, same draws, same order of additions: every bit of the
+    three layers and every counter -- with and without an emitter (the emitter sample of a scattering vertex, tr_emit, the
+    surface's one-sample mixture), across launch splits."""
+    s = scenes.dragon_fog(128, 72, 40, 44, emitter=emitter)
+    assert api.pack_info(s).n_nodes_main > 512
+    out = []
+    for flags in (0, abi.FLAG_NO_RESTART):
+        with api.Renderer(s, flags=flags | abi.FLAG_COUNTERS) as r:
+            r.render(0, 5)
+            r.render(5, 3)
+            out.append(([r.download(k) for k in range(3)], r.stats().as_dict()))
+    (a, sa), (b, sb) = out
+    for k in range(3):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=f"layer {k}")
+    for k in ("rays_closest", "rays_shadow", "rays_emitter", "paths", "hits", "adds", "node_visits", "prim_tests"):
+        assert sa[k] == sb[k], k
+    assert np.isfinite(a[0]).all() and a[0].sum() > 0 and sa["rays_shadow"] > 0 and (sa["rays_emitter"] > 0) == emitter
+
+
+def test_volpath_restart_kernel_against_the_oracle(oracle_mod):
+    s = scenes.dragon_fog(128, 72, 40, 44)
+    sg, so = _compare(s, 8, oracle_mod, frac=5e-3, relmse=1e-3, ctol=2e-3)
+    assert sg["rays_emitter"] > 0 and sg["rays_shadow"] > sg["rays_closest"] * 0.5
+    # the production instantiation (no counters, first-hit layers on) against the counting one
+    with api.Renderer(s) as a, api.Renderer(s, flags=abi.FLAG_COUNTERS) as b:
+        a.render(0, 6)
+        b.render(0, 6)
+        for k in range(3):
+            np.testing.assert_array_equal(a.download(k), b.download(k))
+
+
+def test_volpath_full_size_dragon_fog_holds_its_invariants():
+    """1920 x 1080, 870 k triangles, fog: finite and non-empty, a job cut into launches is bit-identical, paths = pixels x frames."""
+    s = scenes.dragon_fog(1920, 1080)
+    with api.Renderer(s) as r:
+        r.render(0, 4)
+        whole = r.download(0)
+        st = r.stats().as_dict()
+        r.reset()
+        r.render(0, 1)
+        r.render(1, 3)
+        assert np.array_equal(r.download(0), whole)
+    assert st["paths"] == 1920 * 1080 * 4 and np.isfinite(whole).all() and whole.mean() > 0

@@ -33,6 +33,9 @@ def scene_table():
         "fog": (lambda: scenes.cornell_fog(1024, 1024), 16, 0),
         "media-zoo": (lambda: scenes.media_zoo(1024, 768), 16, 0),
         "cornell-vol": (vol_cornell, 32, 0),
+        "dragon-fog": (lambda: scenes.dragon_fog(1920, 1080), 64, 0),
+        "dragon-fog-ww": (lambda: scenes.dragon_fog(1920, 1080), 64, abi.FLAG_NO_RESTART),
+        "dragon-ww": (lambda: scenes.dragon_class(1920, 1080), 64, abi.FLAG_NO_RESTART),
         "cornell-bvh": (lambda: scenes.cornell_box(1024, 1024), 64, abi.FLAG_FORCE_BVH),
         "veach-bvh": (lambda: scenes.veach_mis(1024, 1024), 64, abi.FLAG_FORCE_BVH),
     }
@@ -45,7 +48,7 @@ def rate(names, frames, launches, serial, tune, extra_flags=0):
         mk, F, fl = tab[nm]
         F = frames or F
         s = mk()
-        flags = fl | extra_flags | (0 if serial else abi.FLAG_OVERLAP)
+        flags = fl | extra_flags
         with api.Renderer(s, flags=flags) as r:
             if tune:
                 r.tune(F)
@@ -58,7 +61,7 @@ def rate(names, frames, launches, serial, tune, extra_flags=0):
             r.sync()
             wall = time.perf_counter() - t0
             st = r.stats()
-        print(f"{nm}: {st.rays / wall / 1e6:.0f} Mrays/s wall ({'serial' if serial else 'overlapped'}, {launches} x {F} frames, "
+        print(f"{nm}: {st.rays / wall / 1e6:.0f} Mrays/s wall ({launches} x {F} frames, "
               f"{wall * 1e3 / launches:.2f} ms/launch wall, {st.kernel_ms / st.launches:.2f} ms events), {wall * 1e3 / st.frames:.4f} ms/frame, "
               f"rays/path {st.rays / st.paths:.2f}", flush=True)
 
