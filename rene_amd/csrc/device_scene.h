@@ -304,7 +304,7 @@ struct RenderParams {
   uint32_t n_levels;       // every pixel's frames are cut into n_levels work items (ordered hand-off): n_uniform items of level_step
                            // frames, then the rest in halving items (device_code.inc, item_frames)
   uint32_t epoch;          // launch number (1 .. MAX_EPOCH); a pixel record's version is epoch << VERSION_LEVEL_BITS | items committed
-  uint32_t* item_done;     // [n_work] the same versions for the traversal-restart kernels, whose records are 12 bytes
+  uint32_t* item_done;     // [H][W] the same versions for the traversal-restart kernels, whose records are 12 bytes
   uint32_t ready_min;      // traversal-restart kernel: lanes waiting before the logic step runs
   uint32_t leaf_min;       // traversal-restart kernel: lanes at a leaf before the leaf step runs
   uint32_t level_step;     // frames per uniform work item: item (level < n_uniform, pixel) renders frames [level * step, (level + 1) * step)

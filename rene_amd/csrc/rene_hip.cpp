@@ -198,7 +198,7 @@ struct rene_ctx {
   static constexpr uint32_t kWholeLaunch = 0xffffffffu;
   uint32_t item_frames = 0;
   std::vector<uint32_t> inst_material;  // material index of every instance (rene_bsdf_eval looks an instance of its material up)
-  uint32_t* d_item_done = nullptr;  // [n_work] versions, traversal-restart kernels only (device_code.inc, item_flag_publish)
+  uint32_t* d_item_done = nullptr;  // [H][W] versions, traversal-restart kernels only (device_code.inc, item_flag_publish)
   unsigned long long* d_counters = nullptr;
   // stage-separated wavefront integrator (BVH scenes): path state in HBM + a pinned word for the host loop
   bool wavefront = false;
@@ -328,8 +328,8 @@ struct rene_ctx {
         if (std::getenv("RENE_DEBUG")) {
           unsigned long long t[4] = {0, 0, 0, 0};
           hipMemcpy(t, d_counters + 8, sizeof(t), hipMemcpyDeviceToHost);
-          std::fprintf(stderr, "[rene] %llu work items were dropped (the first: work id %llu of %u slots per level, in launch %llu, wanted version %llu, saw %llu): launching the last %zu launch(es), %u..%u, again, serially (attempt %d)\n",
-                       dropped, t[1], n_work, t[2] >> 32, t[3], t[2] & 0xffffffffull, pending.size(), pending.front().epoch, pending.back().epoch, attempt + 1);
+          std::fprintf(stderr, "[rene] %llu work items were dropped (the first: pixel (%llu, %llu), in launch %llu, wanted version %llu, saw %llu): launching the last %zu launch(es), %u..%u, again, serially (attempt %d)\n",
+                       dropped, t[1] & 0xffffull, t[1] >> 16, t[2] >> 32, t[3], t[2] & 0xffffffffull, pending.size(), pending.front().epoch, pending.back().epoch, attempt + 1);
         }
         HIP_TRY(zero_now(d_counters + 8, 4 * sizeof(unsigned long long)));
         for (Pending& p : pending) {
@@ -365,7 +365,7 @@ struct rene_ctx {
       HIP_TRY(hipMemcpy(t, d_counters + 8, sizeof(t), hipMemcpyDeviceToHost));
       handoff_failed = t[0] != 0;
       if (handoff_failed)
-        handoff_detail = " [" + std::to_string(t[0]) + " lanes gave up; the first: work id " + std::to_string(t[1]) + " of " + std::to_string(n_work) + " slots per level, in launch " +
+        handoff_detail = " [" + std::to_string(t[0]) + " lanes gave up; the first: pixel (" + std::to_string(t[1] & 0xffffull) + ", " + std::to_string(t[1] >> 16) + "), in launch " +
                          std::to_string(t[2] >> 32) + ", wanted version " + std::to_string(t[3]) + ", saw " + std::to_string(t[2] & 0xffffffffu) + "]";
     }
     if (handoff_failed) return fail(RENE_ERR_DEVICE, "work items were dropped inside the render kernel and replaying their launches did not complete them (results invalid; rene_reset clears the condition)" + handoff_detail);
@@ -631,8 +631,8 @@ static int rene_create_impl(const rene_scene_desc* scene, const rene_opts* opts,
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_work_counters), rene_ctx::kCounters * sizeof(uint32_t)));
   HIP_TRY(hipMemsetAsync(c->d_work_counters, 0, rene_ctx::kCounters * sizeof(uint32_t), c->stream));
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_counters), 32 * sizeof(unsigned long long)));
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_item_done), std::max<size_t>(1, c->n_work) * sizeof(uint32_t)));
-  HIP_TRY(hipMemsetAsync(c->d_item_done, 0, std::max<size_t>(1, c->n_work) * sizeof(uint32_t), c->stream));
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_item_done), (size_t)ps.width * ps.height * sizeof(uint32_t)));  // one version word per pixel
+  HIP_TRY(hipMemsetAsync(c->d_item_done, 0, (size_t)ps.width * ps.height * sizeof(uint32_t), c->stream));
   HIP_TRY(hipMemsetAsync(c->fb, 0, c->fb_floats * sizeof(float), c->stream));  // main.rs:1229-1237
   HIP_TRY(hipMemsetAsync(c->d_counters, 0, 32 * sizeof(unsigned long long), c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -799,7 +799,7 @@ static int rene_render_impl(rene_ctx* c, uint32_t first_frame, uint32_t n_frames
   P.prev_final = c->prev_final;
   if (c->epoch >= rene::MAX_EPOCH) {  // (drained above) the epoch wraps: every pixel record back to version 0
     hipMemset2DAsync(c->fb + 3, 4 * sizeof(float), 0, sizeof(float), c->fb_floats / 4, stream);
-    hipMemsetAsync(c->d_item_done, 0, std::max<size_t>(1, c->n_work) * sizeof(uint32_t), stream);
+    hipMemsetAsync(c->d_item_done, 0, (size_t)c->width * c->height * sizeof(uint32_t), stream);
     c->epoch = 0;
     P.prev_final = 0;
   }
@@ -897,7 +897,7 @@ int rene_reset(rene_ctx* c) {
   c->exchanged = false;
   HIP_TRY(hipMemsetAsync(c->fb, 0, c->fb_floats * sizeof(float), c->stream));
   HIP_TRY(hipMemsetAsync(c->d_counters, 0, 32 * sizeof(unsigned long long), c->stream));
-  HIP_TRY(hipMemsetAsync(c->d_item_done, 0, std::max<size_t>(1, c->n_work) * sizeof(uint32_t), c->stream));
+  HIP_TRY(hipMemsetAsync(c->d_item_done, 0, (size_t)c->width * c->height * sizeof(uint32_t), c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->prev_final = 0;  // the pixel records carry version 0 again
   c->frames = 0;
