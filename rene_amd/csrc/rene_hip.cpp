@@ -756,12 +756,12 @@ static int rene_render_impl(rene_ctx* c, uint32_t first_frame, uint32_t n_frames
   // them cut into halving items down to `tail` frames; RENE_LEVELS=<n> (tests, A/B measurements) cuts into n uniform items
   {
     const uint32_t F = P.n_frames;
-    // untuned: a dozen items per pixel and launch for the item-loop kernels, 32 for the BVH kernels, at least 16 frames each
+    // untuned: sixteen items per pixel and launch for the item-loop kernels, 32 for the BVH kernels, at least 16 frames each
     // (measured, one launch per job, MI355X: Cornell 1024 frames flat from 64 to 96 frames per item, veach-mis 4096 frames best at
     // 256 - 341, dragon-class 1024 at 32, the teapot scene 8192 at 256: it is the number of item switches per pixel that a launch
     // pays for, and the length of its last item -- and a BVH scene's pixels differ more in cost);
     // no halving tail by default (tail = item): it buys nothing once the hand-off waits are rare
-    uint32_t item = c->item_frames ? c->item_frames : std::max(16u, F / ((c->cfg.features & rene::FEAT_SMALL) ? 12u : 32u));
+    uint32_t item = c->item_frames ? c->item_frames : std::max(16u, F / ((c->cfg.features & rene::FEAT_SMALL) ? 16u : 32u));
     uint32_t tail = item;
     if (const char* e = std::getenv("RENE_ITEM_FRAMES")) item = (uint32_t)std::max(1, std::atoi(e));  // tuning knobs
     if (const char* e = std::getenv("RENE_ITEM_TAIL")) tail = (uint32_t)std::max(1, std::atoi(e));
