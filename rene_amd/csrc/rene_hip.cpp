@@ -642,6 +642,8 @@ static int rene_create_impl(const rene_scene_desc* scene, const rene_opts* opts,
     hipHostFree(c->h_upload);
     c->h_upload = nullptr;
   }
+  // tests: start the launch numbering just below the wrap of the 22-bit epoch (MAX_EPOCH), so that a handful of launches cross it
+  if (const char* e = std::getenv("RENE_TEST_EPOCH")) c->epoch = (uint32_t)std::min<unsigned long>(rene::MAX_EPOCH, std::strtoul(e, nullptr, 0));
   cleanup.armed = false;
   *out = c.release();
   return RENE_OK;

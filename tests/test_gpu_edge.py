@@ -166,3 +166,71 @@ def test_box_item_merging_on_random_parallelepipeds(oracle_mod, seed):
     np.testing.assert_allclose(hg["t"][same], ho["t"][same], rtol=5e-5, atol=5e-5)
     np.testing.assert_allclose(hg["u"][same], ho["u"][same], atol=2e-4)
     np.testing.assert_allclose(hg["v"][same], ho["v"][same], atol=2e-4)
+
+
+# ---- round 3: long launches, seed tables, the epoch's wrap ---------------------------------------------------------------------
+@pytest.mark.parametrize("bvh", [False, True])
+def test_long_launches_and_their_seed_tables(oracle_mod, monkeypatch, bvh):
+    """One launch renders a whole job.  Up to 1024 frames its seeds sit in LDS one per frame; beyond, as two-level tables
+    (the generator's state every 2^s frames + the affine map of j < 2^s frame steps, device_scene.h SEED_TAB_*); with no room in
+    LDS every path start composes the jump itself (RENE_NO_LDS_SEEDS): all three must draw the same seeds -- bit-identical images,
+    also against launches cut differently, and T1 against the oracle's frames 0 .. 1499."""
+    s = scenes.cornell_box(24, 16)
+    flags = abi.FLAG_FORCE_BVH if bvh else 0
+    with api.Renderer(s, flags=flags) as r:
+        r.render(0, 1500)  # two-level tables
+        whole = [r.download(l) for l in range(3)]
+        r.reset()
+        r.render(0, 700)   # direct tables
+        r.render(700, 800)
+        for l in range(3):
+            assert np.array_equal(r.download(l), whole[l])
+    monkeypatch.setenv("RENE_NO_LDS_SEEDS", "1")
+    with api.Renderer(s, flags=flags) as r:
+        r.render(0, 1500)
+        for l in range(3):
+            assert np.array_equal(r.download(l), whole[l])
+    monkeypatch.delenv("RENE_NO_LDS_SEEDS")
+    o = oracle_mod.Oracle(s)
+    o.render(0, 1500)
+    ref = o.download(0)
+    assert float(((whole[0] - ref) ** 2).sum() / (ref ** 2).sum()) < 1e-4
+    # frame shards deal frames round-robin: the tables then step by `shard_count` frames
+    acc = np.zeros_like(whole[0])
+    for rank in range(3):
+        with api.Renderer(s, flags=flags, shard_mode=abi.SHARD_FRAMES, shard_rank=rank, shard_count=3) as r:
+            r.render(0, 1500)
+            acc += r.download(0)
+    np.testing.assert_allclose(acc, whole[0], rtol=2e-5, atol=1e-4)
+
+
+def test_requests_longer_than_a_launch_are_cut(oracle_mod):
+    """rene_render(first, n) with n beyond 65 536 frames (the most one launch's seed tables cover) becomes several launches."""
+    s = scenes.cornell_box(8, 8)
+    with api.Renderer(s) as r:
+        r.render(0, 70000)
+        a, st = r.download(0), r.stats().as_dict()
+        r.reset()
+        r.render(0, 65536)
+        r.render(65536, 70000 - 65536)
+        assert np.array_equal(r.download(0), a)
+    assert st["launches"] == 2 and st["frames"] == 70000 and st["paths"] == 64 * 70000
+
+
+@pytest.mark.parametrize("bvh", [False, True])
+def test_the_epoch_wraps_without_a_trace(monkeypatch, bvh):
+    """A pixel record's version is epoch << 10 | items committed; after 2^22 - 1 launches the epoch starts again and the version
+    words are cleared.  RENE_TEST_EPOCH starts a context four launches below the wrap: ten launches across it give the image of
+    a fresh context, bit for bit."""
+    s = scenes.cornell_box(64, 48)
+    flags = abi.FLAG_FORCE_BVH if bvh else 0
+    with api.Renderer(s, flags=flags) as r:
+        for k in range(10):
+            r.render(6 * k, 6)
+        want = [r.download(l) for l in range(3)]
+    monkeypatch.setenv("RENE_TEST_EPOCH", str((1 << 22) - 1 - 4))
+    with api.Renderer(s, flags=flags) as r:
+        for k in range(10):
+            r.render(6 * k, 6)
+        for l in range(3):
+            assert np.array_equal(r.download(l), want[l])
