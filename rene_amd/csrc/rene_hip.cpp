@@ -811,7 +811,7 @@ static int rene_render_impl(rene_ctx* c, uint32_t first_frame, uint32_t n_frames
   // swept with the BVH4 (tools/dev_sweep4.py): dragon-class (Matte) peaks at 24 / 12 (4.96 Grays/s; 20 / 16 gave 4.6);
   // teapot-class, whose logic step is the general-BSDF one, keeps gaining up to ~44 waiting lanes (5.3 vs 4.7)
   P.ready_min = (c->cfg.features & rene::FEAT_GENERAL_BSDF) ? 40 : 24;
-  P.leaf_min = 12;
+  P.leaf_min = 6;  // re-swept in round 3 on whole one-launch jobs: flat from 2 to 12 (dragon-class 686 - 689 ms, the teapot scene 3748 - 3789)
   if (const char* e = std::getenv("RENE_READY_MIN")) P.ready_min = (uint32_t)std::max(1, std::atoi(e));  // tuning knobs
   if (const char* e = std::getenv("RENE_LEAF_MIN")) P.leaf_min = (uint32_t)std::max(1, std::atoi(e));
   if (c->wavefront) {
