@@ -147,7 +147,7 @@ Rccl* rccl() {
 
 
 // Host-side waits poll (hipEventQuery / hipStreamQuery read the completion signal) instead of blocking in the runtime: a
-// blocked wait depends on a wake-up from the driver, and on this pool a job of many overlapped launches was seen to sit in
+// blocked wait depends on a wake-up from the driver, and on this pool a job of many launches was seen to sit in
 // one for minutes now and then; polling costs one host thread a few microseconds of latency.
 static hipError_t wait_event(hipEvent_t ev) {
   const auto t0 = std::chrono::steady_clock::now();

@@ -1,5 +1,5 @@
 """-m gpu: random small scenes through every scheduling of the integrator (tools/fuzz_kernels.py): item loop,
-while-while BVH, traversal restart, wavefront, with overlapping launches and other work-item cuts.  Matte scenes agree
+while-while BVH, traversal restart, wavefront, with the (ignored) overlap flag and other work-item cuts.  Matte scenes agree
 bit for bit, general ones to a last bit, the item-loop family with the BVH family and the oracle statistically (T1)."""
 import os
 import subprocess

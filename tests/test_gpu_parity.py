@@ -236,7 +236,7 @@ def test_long_short_work_items_are_bit_identical_to_one_item_per_pixel(res, fram
 
 
 def test_overlap_with_shards_resets_and_a_caller_owned_image():
-    """RENE_FLAG_OVERLAP next to the other ways a context is driven: tile and frame shards, a reset between
+    """RENE_FLAG_OVERLAP (accepted and ignored since ABI v4: launches are serial) next to the other ways a context is driven: tile and frame shards, a reset between
     batches of launches, an image the caller owns (opts.framebuffer: the versions live in its fourth floats),
     counters.  Everything equals the one-launch-at-a-time result bit for bit."""
     import torch
@@ -287,7 +287,7 @@ def test_overlap_with_shards_resets_and_a_caller_owned_image():
 
 
 def test_cornell_512_at_64_spp_overlapped_and_tuned_against_the_oracle(oracle_mod):
-    """The configuration the bench runs in -- overlapping launches, work items cut by rene_tune -- at a size the
+    """The configuration round 2's bench ran in -- the overlap flag (ignored since ABI v4), work items cut by rene_tune -- at a size the
     oracle still finishes in seconds on the box's host cores (17 M paths): T1 on all three layers, counters equal
     to a few paths that forked, mean radiance within 2e-4."""
     s = scenes.cornell_box(512, 512)
@@ -313,7 +313,7 @@ def test_dropped_work_items_are_replayed_bit_identically(monkeypatch, name):
     """A launch is restartable: an item whose hand-off does not come is dropped (not rendered on top of sums that are not its
     own), every waiter after it drops too, and the next sync launches the launches since the last sync again, alone and in
     order; what was committed the first time is skipped.  RENE_TEST_DROP=<n> makes the context's n-th launch drop one item
-    in 97 as if it had timed out -- with launches overlapped, in the middle of a job.  The image and the ray counts must
+    in 97 as if it had timed out -- in the middle of a job.  The image and the ray counts must
     equal an undisturbed render's, on both kernel families."""
     s = {"cornell": lambda: scenes.cornell_box(160, 128), "dragon": lambda: scenes.dragon_class(160, 90, 40, 44),
          "teapot": lambda: scenes.teapot_class(128, 72, 20, 22)}[name]()

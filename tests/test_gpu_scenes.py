@@ -156,11 +156,11 @@ def test_wavefront_equals_megakernels_bit_for_bit(name):
 
 
 @pytest.mark.parametrize("name", ["cornell", "cornell-bvh", "veach", "dragon", "teapot", "fog", "zoo", "zoo-bvh", "media-zoo"])
-def test_overlapping_launches_are_bit_identical(name):
-    """RENE_FLAG_OVERLAP: consecutive launches alternate between two streams, so a launch starts while the previous
-    one is still draining its longest paths.  A pixel's running sums pass from launch to launch through the
-    item_done[] flags on the device (item_publish / item_ready), so the order of additions -- and every bit of
-    the three layers and the counters -- is the one of back-to-back launches on one stream."""
+def test_the_overlap_flag_is_accepted_and_changes_nothing(name):
+    """RENE_FLAG_OVERLAP (ABI <= 3: consecutive launches on two streams) is accepted and ignored since ABI v4: launches are
+    serial, a pixel's running sums pass from launch to launch through the version its records carry, and every bit of the
+    three layers and the counters is the same with and without the flag -- on every kernel family, over launches of mixed
+    lengths, with a second batch after a sync."""
     s, flags = {"cornell": (lambda: scenes.cornell_box(256, 256), 0),
                 "cornell-bvh": (lambda: scenes.cornell_box(128, 128), abi.FLAG_FORCE_BVH | abi.FLAG_NO_RESTART),
                 "veach": (lambda: scenes.veach_mis(192, 128), 0),
@@ -283,7 +283,7 @@ def test_dragon_partial_real_meshes_against_the_oracle(oracle_mod):
 @pytest.mark.parametrize("name", ["dragon-class", "teapot-full"])
 def test_full_size_configs_hold_their_invariants(name):
     """C4 / C5 at 1920x1080 (the oracle would take minutes here): what does not depend on size -- the image is finite and
-    non-empty, a job cut into launches, into overlapping launches and into tile shards is bit-identical, paths = pixels x
+    non-empty, a job cut into launches (with and without the ignored overlap flag) and into tile shards is bit-identical, paths = pixels x
     frames, and the per-ray statistics equal those of the size the oracle checks."""
     big = scenes.dragon_class(1920, 1080) if name == "dragon-class" else scenes.teapot_full(1920, 1080)
     small = scenes.dragon_class(240, 136) if name == "dragon-class" else scenes.teapot_full(192, 108)

@@ -2,7 +2,7 @@
 """Developer measurements on a GPU box (one script; `gpurun -- python3 tools/dev.py <command> ...`).
 
   rate NAME... [--frames F] [--launches N] [--serial] [--no-tune]   wall-clock Mrays/s of bench.py's configurations
-        (plus zoo, fog, media-zoo, veach-bvh, cornell-bvh), launches overlapped unless --serial
+        (plus zoo, fog, media-zoo, dragon-fog, veach-bvh, cornell-bvh), launches one after the other
   sweep VAR V1,V2,... NAME [rate options]                           the same once per value of an environment knob
         (RENE_LEVELS, RENE_READY_MIN, RENE_LEAF_MIN, RENE_BLOCKS_PER_CU, ...): fresh process per value
   soak                                                               C4 / C5 at their full sample counts: no hand-off may time out
@@ -91,7 +91,7 @@ def main():
         from rene_amd import abi, api, scenes
         for nm, s, spp, F in (("dragon-class 1920x1080 @ 1024 spp", scenes.dragon_class(1920, 1080), 1024, 64),
                               ("teapot-class 1920x1080 @ 8192 spp", scenes.teapot_class(1920, 1080), 8192, 128)):
-            with api.Renderer(s, flags=abi.FLAG_OVERLAP) as r:
+            with api.Renderer(s) as r:
                 r.tune(F)
                 t0 = time.perf_counter()
                 for f in range(0, spp, F):

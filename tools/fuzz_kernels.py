@@ -1,6 +1,6 @@
 """Developer script: random small scenes (triangle soups, quads, spheres, every single-lobe material mix, emitters, distant
 lights, backgrounds) rendered by every scheduling that can take them -- item loop, while-while BVH, traversal-restart,
-wavefront -- with and without overlapping launches and across work-item cuts.  Matte-only scenes must agree bit for bit;
+wavefront -- with and without the overlap flag (ignored since ABI v4) and across work-item cuts.  Matte-only scenes must agree bit for bit;
 general ones to a last bit (the restart kernel re-derives the surface after a shadow query).  Against the oracle: T1."""
 import os, sys
 import numpy as np
