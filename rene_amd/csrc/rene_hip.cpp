@@ -763,7 +763,9 @@ static int rene_render_impl(rene_ctx* c, uint32_t first_frame, uint32_t n_frames
     // 256 - 341, dragon-class 1024 at 32, the teapot scene 8192 at 256: it is the number of item switches per pixel that a launch
     // pays for, and the length of its last item -- and a BVH scene's pixels differ more in cost);
     // no halving tail by default (tail = item): it buys nothing once the hand-off waits are rare
-    uint32_t item = c->item_frames ? c->item_frames : std::max(16u, F / ((c->cfg.features & rene::FEAT_SMALL) ? 16u : 32u));
+    // (short launches -- one rank's share of a multi-GPU job -- want few, long items: Cornell 128 frames, 8 / 16 / 32 / 64 frames per
+    // item: 6.89 / 6.59 / 6.59 / 6.41 ms; 256 frames, 16 / 32 / 64 / 128: 13.30 / 13.13 / 13.21 / 12.84; 512 frames, 32 / 64 / 128: 24.93 / 24.74 / 25.23)
+    uint32_t item = c->item_frames ? c->item_frames : ((c->cfg.features & rene::FEAT_SMALL) ? std::max(64u, F / 16u) : std::max(16u, F / 32u));
     uint32_t tail = item;
     if (const char* e = std::getenv("RENE_ITEM_FRAMES")) item = (uint32_t)std::max(1, std::atoi(e));  // tuning knobs
     if (const char* e = std::getenv("RENE_ITEM_TAIL")) tail = (uint32_t)std::max(1, std::atoi(e));

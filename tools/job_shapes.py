@@ -20,6 +20,7 @@ def main():
     cfgs = bench.configurations()
     for nm in names:
         lab, mk, spp, fpl = cfgs[nm]
+        spp = int(os.environ.get("SPP", spp))  # e.g. SPP=128: one rank's share of the 8-GPU strong-scaling job
         sc = mk()
         pk = sc if hasattr(sc, "byref") else sc.to_desc()
         small = nm in ("cornell", "veach-mis")

@@ -1,14 +1,7 @@
-mkdir -p gpurun_out/r3p
-L=gpurun_out/r3p/thresholds2.log
+mkdir -p gpurun_out/r3q
+L=gpurun_out/r3q/short.log
 : > $L
-for lm in 2 4 6 8; do
-echo "-- LEAF_MIN=$lm (READY_MIN default)" >> $L
-RENE_LEAF_MIN=$lm SHAPES=1024:i32/32 python3 tools/job_shapes.py dragon-class 2>&1 | grep -v amdgpu.ids >> $L
-RENE_LEAF_MIN=$lm SHAPES=8192:i256/256 python3 tools/job_shapes.py teapot-class 2>&1 | grep -v amdgpu.ids >> $L
-done
-for v in ns2 ns4; do
-echo "-- node steps per iteration: variant $v, LEAF_MIN=8" >> $L
-RENE_HIP_LIB=librene_hip_$v.so RENE_LEAF_MIN=8 SHAPES=1024:i32/32 python3 tools/job_shapes.py dragon-class 2>&1 | grep -v amdgpu.ids >> $L
-RENE_HIP_LIB=librene_hip_$v.so RENE_LEAF_MIN=8 SHAPES=8192:i256/256 python3 tools/job_shapes.py teapot-class 2>&1 | grep -v amdgpu.ids >> $L
-done
+SPP=128 SHAPES=128:i8/8,128:i16/16,128:i32/32,128:i64/64,128:w python3 tools/job_shapes.py cornell 2>&1 | grep -v amdgpu.ids >> $L
+SPP=256 SHAPES=256:i16/16,256:i32/32,256:i64/64,256:i128/128 python3 tools/job_shapes.py cornell 2>&1 | grep -v amdgpu.ids >> $L
+SPP=512 SHAPES=512:i32/32,512:i64/64,512:i128/128 python3 tools/job_shapes.py cornell 2>&1 | grep -v amdgpu.ids >> $L
 cat $L
