@@ -1,7 +1,11 @@
-mkdir -p gpurun_out/r3q
-L=gpurun_out/r3q/short.log
-: > $L
-SPP=128 SHAPES=128:i8/8,128:i16/16,128:i32/32,128:i64/64,128:w python3 tools/job_shapes.py cornell 2>&1 | grep -v amdgpu.ids >> $L
-SPP=256 SHAPES=256:i16/16,256:i32/32,256:i64/64,256:i128/128 python3 tools/job_shapes.py cornell 2>&1 | grep -v amdgpu.ids >> $L
-SPP=512 SHAPES=512:i32/32,512:i64/64,512:i128/128 python3 tools/job_shapes.py cornell 2>&1 | grep -v amdgpu.ids >> $L
-cat $L
+mkdir -p gpurun_out/r3s
+python -m pytest tests -m gpu -x -q > gpurun_out/r3s/pytest.log 2>&1; tail -3 gpurun_out/r3s/pytest.log
+python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tail -2
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r3s/bench.json 2> gpurun_out/r3s/bench.err; python3 - <<'PY'
+import json
+d=json.loads([l for l in open("gpurun_out/r3s/bench.json") if l.startswith('{"metric"')][-1])
+rl=d["roofline"]
+print("headline", round(d["value"]), "Mrays/s", "step median", round(d["step_ms_median"],2), "min", round(d["step_ms_min"],2), "ms_per_step", round(d["ms_per_step"],2), "sclk", round(rl["sclk_mhz"]), "identical", d["jobs_bit_identical"], "frac", round(rl["frac"],3), "useful", round(rl["useful_lane_frac"],3), "stale", rl["pmc_stale"], "launch_ms", round(rl["launch_ms"],2))
+for k,v in d["configs"].items(): print(k, round(v.get("value",0)), v.get("seconds"), (v.get("valu") or {}).get("frac"), (v.get("valu") or {}).get("useful_lane_frac"), (v.get("hbm") or {}).get("frac"), v.get("error"))
+print(d["cpu_baseline"])
+PY
