@@ -73,6 +73,8 @@ def configurations():
         "dragon-class": ("dragon-class (870 400 triangles, one distant light) 1920x1080 @ 1024 spp", lambda: scenes.dragon_class(1920, 1080), 1024, 1024),
         "dragon-partial": ("rene's sample_scenes/dragon with the 12 meshes its checkout holds (51 140 triangles, one distant light) through the "
                            "pbrt loader, 1280x720 @ 1024 spp", lambda: scenes.dragon_partial(1280, 720), 1024, 1024),
+        "material-zoo": ("material zoo (all seven materials incl. the multi-lobe Uber / Plastic, checkerboard / imagemap / scale textures, spheres, "
+                         "an environment light: the five-lobe kernels) 1024x768 @ 256 spp", lambda: scenes.material_zoo(1024, 768), 256, 256),
         "teapot-class": ("teapot-full-class: rene's sample_scenes/teapot (126 050 triangles, Substrate + checkerboard + env map) through the "
                          "pbrt loader, synthetic 1024x512 sky, 1920x1080 @ 8192 spp", lambda: scenes.teapot_full(1920, 1080), 8192, 8192),
     }

@@ -15,11 +15,11 @@ import bench  # noqa: E402
 
 def test_configurations_and_records():
     cfgs = bench.configurations()
-    assert list(cfgs)[0] == "cornell" and set(cfgs) == {"cornell", "veach-mis", "dragon-class", "dragon-partial", "teapot-class"}
+    assert list(cfgs)[0] == "cornell" and set(cfgs) == {"cornell", "veach-mis", "dragon-class", "dragon-partial", "material-zoo", "teapot-class"}
     for name, (label, make, spp, fpl) in cfgs.items():
         assert spp == fpl and callable(make) and str(spp) in label  # one launch per job
         rec = bench.pmc_per_ray(name)
-        if name == "dragon-partial":  # timed only: no PMC passes of its own
+        if name in ("dragon-partial", "material-zoo"):  # timed only: no PMC passes of their own
             continue
         assert rec and rec["valu_wave_insts_per_ray"] > 0 and os.path.exists(os.path.join(ROOT, rec["source"])), name
 
@@ -37,7 +37,7 @@ def test_pmc_staleness_is_reported():
 
 def test_roofline_fractions_are_fractions():
     for name in bench.configurations():
-        if name == "dragon-partial":
+        if name in ("dragon-partial", "material-zoo"):
             continue
         rl = bench.rooflines(name, 1.0e10 if name != "cornell" else 1.2e11, 256, 500.0)
         assert 0.0 < rl["valu"]["frac"] <= 1.0 and rl["valu"]["peak"] == pytest.approx(78.6432)
@@ -58,5 +58,5 @@ def test_a_failing_or_stalling_configuration_becomes_an_error_entry(monkeypatch,
     out = bench.configs_in_children("cornell", timeout_s=2.0)
     assert out["veach-mis"] == {"value": 1.0}
     assert "exit code 3" in out["dragon-class"]["error"] and "boom" in out["dragon-class"]["stderr_tail"]
-    assert "did not finish" in out["teapot-class"]["error"] and "did not finish" in out["dragon-partial"]["error"]
+    assert "did not finish" in out["teapot-class"]["error"] and "did not finish" in out["dragon-partial"]["error"] and "did not finish" in out["material-zoo"]["error"]
     json.dumps(out)
