@@ -279,7 +279,9 @@ int rene_create(const rene_scene_desc* scene, const rene_opts* opts, rene_ctx** 
 
 /* Replaces the trace loop (rene/src/main.rs:1315-1397): render frames
  * [first_frame, first_frame + n_frames) and add them into the accumulation layers.  Asynchronous
- * on the context's stream; ordered with later calls on the same context. */
+ * on the context's stream; ordered with later calls on the same context.  ONE persistent launch per call (requests beyond
+ * 65 536 frames are cut): a whole job is best rendered by one call -- every call ends on the longest paths of its last work
+ * items -- and the image does not depend on how a job is cut into calls (bit-identical). */
 int rene_render(rene_ctx* ctx, uint32_t first_frame, uint32_t n_frames);
 
 /* Waits for everything queued on the context (queue_wait_idle, main.rs:1389). */
@@ -292,12 +294,13 @@ int rene_download(rene_ctx* ctx, int layer, int channels, float* dst, size_t dst
 /* Zero the accumulation layers and the counters (main.rs:1229-1237). */
 int rene_reset(rene_ctx* ctx);
 
-/* Optional, before rendering: picks how finely a launch of `n_frames` frames cuts a pixel's frames into work items
- * (no reference counterpart; rene dispatches one frame at a time, main.rs:1355-1372).  Few, long items cost the
- * least bookkeeping; short ones balance scenes whose pixels differ widely in cost (a 16-frame launch of the
- * dragon-class scene: 6.0 Grays/s with one item per pixel, 7.9 with eight).  Renders a few launches of
- * `n_frames` frames per candidate, keeps the fastest, then resets the context like rene_reset.  The choice changes
- * no bit of any image -- a pixel's frames are added in the same order however they are cut. */
+/* Optional, before rendering: picks how long the work items of a launch of `n_frames` frames are (no reference counterpart;
+ * rene dispatches one frame at a time, main.rs:1355-1372).  Few, long items cost the least bookkeeping; short ones balance
+ * scenes whose pixels differ widely in cost and end the launch on a short tail.  Renders three launches of `n_frames` frames
+ * per candidate (one item per pixel and launch, then items of 256, 128, ... 16 frames), keeps the fastest, then resets the
+ * context like rene_reset.  Untuned contexts use n_frames / 16 frames per item (at least 64) with the small-scene kernels and
+ * n_frames / 32 (at least 16) with the BVH kernels.  The choice changes no bit of any image -- a pixel's frames are added in
+ * the same order however they are cut. */
 int rene_tune(rene_ctx* ctx, uint32_t n_frames);
 
 /* Device address of the accumulation image [3][yres][xres][4] f32 (for callers that run their own exchange, e.g.
