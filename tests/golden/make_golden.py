@@ -64,6 +64,35 @@ def main():
     with open(os.path.join(HERE, "cornell_camera_rays.json"), "w") as f:
         json.dump(rays, f, indent=1)
 
+    # per-function vectors of every material kind ("per-function vectors for each BxDF / microfacet / Fresnel function
+    # from the CPU oracle"): inputs + the oracle's f, pdf, sample_f for 48 well-conditioned configurations per material
+    out = {}
+    for tag, scene, mats in (("zoo", scenes.material_zoo(32, 32), (1, 2, 3, 4, 5, 6, 7, 8, 10)), ("veach", scenes.veach_mis(32, 32), (1, 2, 3, 4, 6))):
+        oo = oracle.Oracle(scene)
+        for m in mats:
+            rng = np.random.default_rng(9000 + m)
+            n = 48
+            nrm = rng.normal(size=(n, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+            loc = lambda: (lambda d: d / np.linalg.norm(d, axis=1, keepdims=True))(np.c_[rng.normal(size=(n, 2)), rng.uniform(0.3, 1.0, n) * rng.choice([-1, 1], n)])
+            wo_l, wi_l = loc(), loc()
+            wo_l[:, 2] = np.abs(wo_l[:, 2])
+            wo, wi = np.zeros((n, 3)), np.zeros((n, 3))
+            for i in range(n):
+                w = nrm[i]
+                a = np.array([0, w[2], -w[1]]) if abs(w[0]) <= abs(w[1]) else np.array([-w[2], 0, w[0]])
+                u = a / np.linalg.norm(a); v = np.cross(w, u)
+                wo[i] = wo_l[i, 0] * u + wo_l[i, 1] * v + wo_l[i, 2] * w
+                wi[i] = wi_l[i, 0] * u + wi_l[i, 1] * v + wi_l[i, 2] * w
+            uv = rng.uniform(0, 1, (n, 2))
+            seeds = rng.integers(0, 2 ** 32, n, dtype=np.uint32)
+            nrm, uv, wo, wi = (x.astype(np.float32) for x in (nrm, uv, wo, wi))
+            res = np.zeros((n, 12), np.float32)
+            for i in range(n):
+                e = oo.bsdf_eval(m, nrm[i], uv[i], wo[i], wi[i], int(seeds[i]))
+                res[i] = np.concatenate([e["f"], [e["pdf"]], e["s_wi"], e["s_f"], [e["s_pdf"]], [e["len"]]])
+            out[f"{tag}_{m}"] = np.concatenate([nrm, uv, wo, wi, seeds.view(np.float32)[:, None], res], axis=1)  # [n][3+2+3+3+1+12]
+    np.savez_compressed(os.path.join(HERE, "bxdf_vectors.npz"), **out)
+
 
 if __name__ == "__main__":
     main()

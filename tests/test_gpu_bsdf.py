@@ -111,3 +111,25 @@ def test_materials_resolved_at_upload_render_bit_identically(monkeypatch):
                 images.append([r.download(l) for l in range(3)])
         for a, b in zip(*images):
             assert np.array_equal(a, b)
+
+
+def test_device_answers_the_committed_per_function_vectors():
+    """tests/golden/bxdf_vectors.npz: the device's rene_bsdf_eval against the COMMITTED answers (no oracle at run time): lobe counts
+    exact, f / pdf to the material's tolerance, samples unless a discrete decision flipped."""
+    import os
+    from conftest import GOLDEN
+    data = np.load(os.path.join(GOLDEN, "bxdf_vectors.npz"))
+    scene = {"zoo": scenes.material_zoo(32, 32), "veach": scenes.veach_mis(32, 32)}
+    tol = {"zoo": {1: 2e-4, 2: 2e-4, 3: 2e-4, 4: 2e-4, 5: 2e-3, 6: 2e-3, 7: 2e-3, 8: 2e-3, 10: 2e-3}, "veach": {1: 2e-4, 2: 5e-2, 3: 2e-2, 4: 5e-3, 6: 2e-3}}
+    for tag in ("zoo", "veach"):
+        with api.Renderer(scene[tag]) as r:
+            for key in [k for k in data.files if k.startswith(tag)]:
+                m = int(key.split("_")[1])
+                v = data[key]
+                g = r.bsdf_eval(m, v[:, 0:3].copy(), v[:, 3:5].copy(), v[:, 5:8].copy(), v[:, 8:11].copy(), v[:, 11].copy().view(np.uint32))
+                want = v[:, 12:]
+                assert np.array_equal(g[:, 11], want[:, 11]), key
+                ok = _close(g[:, :4], want[:, :4], tol[tag][m], atol=1e-5).all(axis=1)
+                assert ok.mean() > 0.95, (key, "f / pdf", ok.mean())
+                ok_s = _close(g[:, 4:11], want[:, 4:11], 10 * tol[tag][m], atol=5e-3).all(axis=1)
+                assert ok_s.mean() > 0.9, (key, "sample", ok_s.mean())

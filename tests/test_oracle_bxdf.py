@@ -201,3 +201,24 @@ def test_textures(oracle_mod):
     np.testing.assert_allclose(o.tex_color(im, 0.25, 0.75), [1, 0, 0], atol=1e-6)
     np.testing.assert_allclose(o.tex_color(im, 0.75, 0.25), [1, 1, 1], atol=1e-6)
     np.testing.assert_allclose(o.tex_color(im, 0.5, 0.75), [0.5, 0.5, 0], atol=1e-6)
+
+
+def test_committed_per_function_vectors(oracle_mod):
+    """tests/golden/bxdf_vectors.npz (per-function vectors of every material kind, written by make_golden.py from this
+    oracle): the oracle still answers them -- f, pdf and sample_f of all seven materials, the zoo's textures underneath, the four
+    veach plates.  Pins the checker against silent change; libm may differ by an ulp across glibc builds."""
+    import os
+    from conftest import GOLDEN
+    from rene_amd import scenes
+    data = np.load(os.path.join(GOLDEN, "bxdf_vectors.npz"))
+    built = {"zoo": oracle_mod.Oracle(scenes.material_zoo(32, 32)), "veach": oracle_mod.Oracle(scenes.veach_mis(32, 32))}
+    assert len(data.files) == 14
+    for key in data.files:
+        tag, m = key.split("_")
+        v = data[key]
+        assert v.shape == (48, 24)
+        for row in v:
+            nrm, uv, wo, wi, seed, want = row[0:3], row[3:5], row[5:8], row[8:11], int(row[11:12].view(np.uint32)[0]), row[12:]
+            e = built[tag].bsdf_eval(int(m), nrm, uv, wo, wi, seed)
+            got = np.concatenate([e["f"], [e["pdf"]], e["s_wi"], e["s_f"], [e["s_pdf"]], [e["len"]]])
+            np.testing.assert_allclose(got, want, rtol=2e-5, atol=1e-6, err_msg=key)
