@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer measurements on a GPU box (one script; `gpurun -- python3 tools/dev.py <command> ...`).
 
-  rate NAME... [--frames F] [--launches N] [--serial] [--no-tune]   wall-clock Mrays/s of bench.py's configurations
+  rate NAME... [--frames F] [--launches N] [--no-tune]   wall-clock Mrays/s of bench.py's configurations
         (plus zoo, fog, media-zoo, dragon-fog, veach-bvh, cornell-bvh), launches one after the other
   sweep VAR V1,V2,... NAME [rate options]                           the same once per value of an environment knob
         (RENE_LEVELS, RENE_READY_MIN, RENE_LEAF_MIN, RENE_BLOCKS_PER_CU, ...): fresh process per value
@@ -88,19 +88,18 @@ def main():
             print(f"{var}={v}: " + " | ".join(l for l in p.stdout.splitlines() if l) + (p.stderr[-300:] if p.returncode else ""), flush=True)
     elif a.command == "soak":
         import numpy as np
-        from rene_amd import abi, api, scenes
-        for nm, s, spp, F in (("dragon-class 1920x1080 @ 1024 spp", scenes.dragon_class(1920, 1080), 1024, 64),
-                              ("teapot-class 1920x1080 @ 8192 spp", scenes.teapot_class(1920, 1080), 8192, 128)):
+        from rene_amd import api, scenes
+        for nm, s, spp in (("dragon-class 1920x1080 @ 1024 spp", scenes.dragon_class(1920, 1080), 1024),
+                           ("teapot-full 1920x1080 @ 8192 spp", scenes.teapot_full(1920, 1080), 8192)):
             with api.Renderer(s) as r:
-                r.tune(F)
                 t0 = time.perf_counter()
-                for f in range(0, spp, F):
-                    r.render(f, F)
+                r.render(0, spp)  # one launch per job
                 r.sync()
                 dt = time.perf_counter() - t0
-                st = r.stats()  # raises if a hand-off timed out
+                st = r.stats()  # raises if a hand-off timed out and its replay did not repair it
                 img = r.download(0)
-            print(f"{nm}: {dt:.2f} s, {st.rays / dt / 1e6:.0f} Mrays/s, {dt * 1e3 / spp:.3f} ms/frame, finite {bool(np.isfinite(img).all())}, mean {img.mean() / spp:.4f}", flush=True)
+            print(f"{nm}: {dt:.2f} s, {st.rays / dt / 1e6:.0f} Mrays/s, {dt * 1e3 / spp:.3f} ms/frame, launches {st.launches} (1 = none replayed), "
+                  f"finite {bool(np.isfinite(img).all())}, mean {img.mean() / spp:.4f}", flush=True)
     elif a.command == "counters":
         from rene_amd import abi, api
         tab = scene_table()
