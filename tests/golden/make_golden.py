@@ -64,6 +64,15 @@ def main():
     with open(os.path.join(HERE, "cornell_camera_rays.json"), "w") as f:
         json.dump(rays, f, indent=1)
 
+    # the volumetric integrator's oracle, pinned the same way: cornell-fog (fog + a dense cloud behind None-material boundaries)
+    sv = scenes.cornell_fog(48, 48)
+    ov = oracle.Oracle(sv)
+    ov.render(0, 4, threads=1)
+    np.save(os.path.join(HERE, "cornell_fog_48x48_4spp_layers.npy"), np.stack([ov.download(l) for l in range(3)]).astype(np.float32))
+    stv = ov.stats().as_dict()
+    with open(os.path.join(HERE, "cornell_fog_48x48_4spp_stats.json"), "w") as f:
+        json.dump({k: stv[k] for k in ("rays_closest", "rays_emitter", "rays_shadow", "paths", "hits", "adds")}, f)
+
     # per-function vectors of every material kind ("per-function vectors for each BxDF / microfacet / Fresnel function
     # from the CPU oracle"): inputs + the oracle's f, pdf, sample_f for 48 well-conditioned configurations per material
     out = {}

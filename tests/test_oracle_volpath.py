@@ -230,3 +230,21 @@ def test_loader_medium_defaults_scoping_and_errors(hip_lib):
     with pytest.raises(api.ReneError) as e:
         loader.parse_pbrt(src.replace('MediumInterface "a" ""', 'MediumInterface "b" ""'))
     assert e.value.code == -2 and "Unknown Medium" in str(e.value)
+
+
+def test_volpath_oracle_matches_its_committed_fixture(oracle_mod):
+    """tests/golden/cornell_fog_48x48_4spp_*: the volumetric integrator's oracle pinned against silent change (written by
+    make_golden.py from this oracle; libm's exp / log may differ by an ulp across glibc builds, a path may then fork)."""
+    import json
+    import os
+    from conftest import GOLDEN
+    o = oracle_mod.Oracle(scenes.cornell_fog(48, 48))
+    o.render(0, 4, threads=1)
+    got = np.stack([o.download(l) for l in range(3)])
+    want = np.load(os.path.join(GOLDEN, "cornell_fog_48x48_4spp_layers.npy"))
+    bad = np.abs(got - want) > 1e-4 * (1 + np.abs(want))
+    assert bad.mean() < 2e-3
+    st = o.stats().as_dict()
+    ref = json.load(open(os.path.join(GOLDEN, "cornell_fog_48x48_4spp_stats.json")))
+    for k, v in ref.items():
+        assert abs(st[k] - v) <= max(4, 1e-4 * v), k
