@@ -132,7 +132,14 @@ def test_wavefront_equals_megakernels_bit_for_bit(name):
             imgs.append([r.download(k) for k in range(3)])
             st = r.stats().as_dict()
             stats.append({k: st[k] for k in ("rays_closest", "rays_shadow", "rays_emitter", "paths", "hits", "adds", "node_visits", "prim_tests")})
-    assert stats[0] == stats[1] == stats[2], stats
+    assert stats[0] == stats[2], stats
+    # the traversal-restart kernel traverses speculatively (render_wf.inc, RENE_WF_POSTPONE): a lane puts its leaf aside and goes on
+    # with inner nodes until the next leaf step -- same leaves in the same order with the same outcome, a few more node visits
+    # and triangle tests (those made before the pending leaf had shortened the ray)
+    exact = ("rays_closest", "rays_shadow", "rays_emitter", "paths", "hits", "adds")
+    assert {k: stats[1][k] for k in exact} == {k: stats[0][k] for k in exact}, stats
+    for k in ("node_visits", "prim_tests"):
+        assert stats[0][k] <= stats[1][k] <= 1.2 * stats[0][k], (k, stats)
     for k in range(3):
         np.testing.assert_array_equal(imgs[0][k], imgs[2][k])  # wavefront == while-while megakernel, always
         if name in ("dragon", "cornell"):

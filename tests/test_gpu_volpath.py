@@ -136,7 +136,7 @@ def test_full_size_fog_is_consistent_with_the_oracle_checked_size():
 def test_volpath_restart_kernel_equals_the_while_while_kernel_bit_for_bit(emitter):
     """A tree of more than 512 nodes renders through render_kernel_wf with the walks (tr / tr_emit) as phases of its state machine;
     RENE_FLAG_NO_RESTART keeps the while-while loop.  Same arithmetic, same draws, same order of additions: every bit of the
-    three layers and every counter -- with and without an emitter (the emitter sample of a scattering vertex, tr_emit, the
+    three layers and every ray / hit / add counter -- with and without an emitter (the emitter sample of a scattering vertex, tr_emit, the
     surface's one-sample mixture), across launch splits."""
     s = scenes.dragon_fog(128, 72, 40, 44, emitter=emitter)
     assert api.pack_info(s).n_nodes_main > 512
@@ -149,8 +149,10 @@ def test_volpath_restart_kernel_equals_the_while_while_kernel_bit_for_bit(emitte
     (a, sa), (b, sb) = out
     for k in range(3):
         np.testing.assert_array_equal(a[k], b[k], err_msg=f"layer {k}")
-    for k in ("rays_closest", "rays_shadow", "rays_emitter", "paths", "hits", "adds", "node_visits", "prim_tests"):
+    for k in ("rays_closest", "rays_shadow", "rays_emitter", "paths", "hits", "adds"):
         assert sa[k] == sb[k], k
+    for k in ("node_visits", "prim_tests"):  # the restart kernel's speculative traversal (render_wf.inc, RENE_WF_POSTPONE) visits a few more
+        assert sb[k] <= sa[k] <= 1.2 * sb[k], k
     assert np.isfinite(a[0]).all() and a[0].sum() > 0 and sa["rays_shadow"] > 0 and (sa["rays_emitter"] > 0) == emitter
 
 
