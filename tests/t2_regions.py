@@ -77,3 +77,25 @@ def region_ratios(mine_rgb8, rene_lin4, regions, min_cells=150):
 
 def describe(ratios):
     return ", ".join(f"inst {r >> 12} quad {r & 4095}: {c} cells, rene {b:.4f}, ratio {q:.4f}" for r, (c, q, b) in sorted(ratios.items()))
+
+
+# ---- rene's dragon render against the 12 of its 16 meshes the checkout holds (tests/golden/dragon_partial) -----------------------
+def dragon_lit_ratio(mine_rgb8, hit_mask):
+    """rene's images/dragon.png is a raw (not denoised) render of sample_scenes/dragon: Matte meshes under ONE distant light on a
+    black background -- the only published image that reaches light.rs' distant light (lib.rs:234-272).  Four of the sixteen meshes
+    are missing from the checkout (the body and two ground pieces), so shadows and interreflections differ wherever they matter;
+    the DIRECTLY LIT surfaces of the meshes that are there do not depend on them to first order.  Over the 4 x 4 cells that this
+    build's first hits cover completely (and whose neighbours they cover too) and that are bright but not saturated in rene's
+    image (sRGB 0.5 .. 0.98), returns (cells, median of the per-cell ratio of linear radiance mine / rene, lower and upper quartile,
+    fraction of the covered cells that lie inside rene's silhouette)."""
+    from scipy import ndimage as ndi
+    a = np.load(os.path.join(GOLDEN, "rene_dragon_box4.npy")).astype(np.float32)
+    rene_srgb, rene_lin = a[0], a[1]
+    mine = mine_rgb8.astype(np.float32).mean(axis=2, keepdims=True) / 255.0
+    mine_lin = box(to_linear(mine), 4)[..., 0]
+    covered = box(hit_mask[..., None].astype(np.float32), 4)[..., 0] == 1.0
+    inner = ndi.binary_erosion(covered, iterations=1)
+    m = inner & (rene_srgb > 0.5) & (rene_srgb < 0.98)
+    r = mine_lin[m] / rene_lin[m]
+    q = np.quantile(r, [0.25, 0.5, 0.75])
+    return int(m.sum()), float(q[1]), float(q[0]), float(q[2]), float((rene_srgb[covered] > 0.02).mean())

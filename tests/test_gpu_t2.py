@@ -121,3 +121,33 @@ def test_t2_veach_mis_at_renes_5000_spp_box4_and_every_surface(oracle_mod):
     print(_show(rows))
     assert rmse < T2_VEACH_BOX4_RMSE
     assert _check_regions(rows, T2_VEACH_RATIOS) >= 20
+
+
+# ---- tier T3: where things are in rene's published teapot render (tests/t3_geometry.py) --------------------------------------
+def test_t3_teapot_geometry_vs_renes_render():
+    """The HIP path's first-hit albedo of one frame of rene's own teapot scene file at its own 1280 x 720 against rene's published
+    render of it, one bit per pixel: checkerboard phase on the floor, the teapot's outline (see test_oracle_render.py's twin)."""
+    import t3_geometry as T
+    with api.Renderer(scenes.teapot_full(1280, 720)) as r:
+        r.render(0, 1)
+        g = T.geometry(r.download(2), T.rene_teapot_bright())
+    print("T3 teapot geometry, GPU vs rene:", g)
+    assert g["floor_pixels"] > 600000 and g["teapot_pixels"] > 200000
+    assert 1.0 - g["checker"] < 4.2e-4  # the oracle's figure: 3.3e-4 (same frame seed, same jitter)
+    assert g["inside"] > 0.9687 and g["outside"] < 0.0102  # oracle: 0.9750 / 0.0081
+
+
+def test_t2_dragon_lit_surfaces_vs_renes_render():
+    """The HIP path on the 12 dragon meshes the checkout holds, at 1280 x 720 x 1024 spp, against rene's raw render of the whole
+    scene: the directly lit surfaces (tests/t2_regions.py, dragon_lit_ratio) -- reference-held radiance for the distant light."""
+    import t2_regions as T
+    spp = 1024
+    with api.Renderer(scenes.dragon_partial(1280, 720)) as r:
+        r.render(0, spp)
+        rgb8 = api.to_rgb8(r.download(0), spp)
+        hit = np.abs(r.download(1)[..., :3]).sum(axis=2) > 0.5 * spp
+    n, med, q1, q3, inside = T.dragon_lit_ratio(rgb8, hit)
+    print(f"T2 dragon (partial), GPU vs rene: {n} lit cells, linear ratio median {med:.4f} quartiles {q1:.4f} / {q3:.4f}, inside rene's silhouette {inside:.4f}")
+    assert n > 3000
+    assert abs(med - 0.993) < 0.01 and q1 > 0.94 and q3 < 1.03  # the oracle at 32 spp: 0.9935, 0.9621 / 1.0074
+    assert inside > 0.95
