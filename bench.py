@@ -34,7 +34,9 @@ The JSON line also carries
                   HBM bytes per ray (FETCH_SIZE x 2 + WRITE_SIZE, same passes) x live rays/s against 8 TB/s, and
                   SURVEY 8d's cache-less algorithmic bytes for comparison (not a fraction of anything: the scene
                   lives in the caches).  `traffic` = measured HBM bytes per launch.
-  configs      -- N = 1 only: the other BASELINE configurations that fit one GPU, one full job each at its own
+  configs      -- N > 1: BASELINE's 8-GPU configurations C4 (dragon-class 1920x1080 @ 1024 spp) and C5 (teapot-class 1920x1080 @ 8192 spp),
+                  one job each, sharded over the N ranks like the headline (frame blocks + one RCCL reduce), max-over-ranks time.
+                  N = 1: the other BASELINE configurations that fit one GPU, one full job each at its own
                   resolution and sample count (C3 veach-mis 1024x1024 @ 4096 spp, C4 dragon-class 1920x1080 @ 1024 spp,
                   C5 teapot-class 1920x1080 @ 8192 spp), each with rays, Mrays/s, ms/frame and the same two fractions.
                   Each runs in a process of its own, before this one touches the GPU, under --config-timeout seconds:
@@ -166,6 +168,83 @@ def run_config(name: str, device: int = 0):
             "launch_ms": s2.kernel_ms / max(1, s2.launches), "launch_period_ms": dt * 1e3 / max(1, s2.launches),
             "kernel": (pmc_per_ray(name) or {}).get("kernel"),
             "valu": rl2["valu"], "hbm": rl2["hbm"]}
+
+
+def run_config_sharded(name: str, local: int, rank: int, world: int, backend: str, in_library: bool, by_tiles: bool):
+    """N > 1: one whole job of one of BASELINE's 8-GPU configurations (C4 dragon-class, C5 teapot-class) sharded over the ranks the
+    way the headline job is -- contiguous frame blocks + one reduce onto rank 0 (or tiles + a gather) -- timed between barriers,
+    max over ranks.  Every rank must take every step (communicator set-up and the exchange are collectives): a step that can fail
+    locally is agreed on first, and a configuration some rank cannot set up is skipped by all."""
+    import torch
+    import torch.distributed as dist
+    from rene_amd import abi, api, dist as rdist
+    lab, mk, spp, fpl = configurations()[name]
+    dev = f"cuda:{local}"
+    ok = torch.ones(1, device=dev)
+    r = fb = None
+    err = ""
+    try:
+        sc = mk()
+        pk = sc if hasattr(sc, "byref") else sc.to_desc()
+        W, H = pk.xres, pk.yres
+        t_rank, t_world = (rank, world) if by_tiles else (0, 1)
+        fb = torch.zeros((3, H, W, 4), dtype=torch.float32, device=dev)
+        r = api.Renderer(pk, device=local, framebuffer_ptr=fb.data_ptr(), shard_mode=abi.SHARD_TILES, shard_rank=t_rank, shard_count=t_world)
+        my_uid = api.comm_unique_id() if in_library else None
+    except Exception as e:  # noqa: BLE001 -- reported in the line
+        err = repr(e)
+        ok.zero_()
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if ok.item() <= 0:
+        if r is not None:
+            r.close()
+        return {"workload": lab, "error": err or "another rank could not set this configuration up"}
+    if in_library:
+        uid = [my_uid if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        r.comm_init(world, rank, uid[0])
+    lo, hi = (0, spp) if by_tiles else rdist.frame_block(rank, world, spp)
+
+    def exchange():
+        if in_library:
+            r.gather_tiles(0) if by_tiles else r.reduce(0)
+            r.sync()
+        elif by_tiles:
+            rdist.gather_owned_tiles(fb, rank, world, dst=0)
+        else:
+            rdist.reduce_framebuffer(fb, dst=0)
+        torch.cuda.synchronize()
+
+    def fence():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    r.render(lo, min(64, hi - lo))  # warm-up: the kernel's code object, the communicator's rings
+    r.sync()
+    exchange()
+    fence()
+    t0 = time.perf_counter()
+    r.reset()
+    r.render(lo, hi - lo)
+    r.sync()
+    exchange()
+    fence()
+    dt = time.perf_counter() - t0
+    st = r.stats()
+    tot = torch.tensor([float(st.rays), float(st.paths)], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    finite = bool(torch.isfinite(fb[0, :, :, :3]).all()) and float(fb[0, :, :, :3].mean()) > 0.0 if rank == 0 else True
+    r.close()
+    dt = float(tmax.item())
+    return {"workload": lab, "n_gpus": world, "width": W, "height": H, "spp": spp, "frames_per_gpu": hi - lo,
+            "sharding": "tiles + gather" if by_tiles else "frame blocks + reduce",
+            "exchange": "RCCL inside librene_hip" if in_library else f"torch.distributed ({backend})",
+            "rays": float(tot[0].item()), "rays_per_path": float(tot[0].item() / max(1.0, tot[1].item())),
+            "value": float(tot[0].item()) / dt / 1e6, "unit": "Mrays/s", "seconds": dt, "ms_per_frame": dt / spp * 1e3,
+            "image_ok": finite}
 
 
 def configs_in_children(head: str, timeout_s: float):
@@ -343,6 +422,14 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     total_rays, elapsed = float(rays.item()), float(tmax.item())
 
+    # N > 1: BASELINE's two 8-GPU configurations (C4, C5), one sharded job each, after the headline's timed region
+    # (RENE_BENCH_MULTI_CONFIGS=0 skips them)
+    multi_configs = None
+    if world > 1 and not args.only and not args.no_configs and os.environ.get("RENE_BENCH_MULTI_CONFIGS", "1") != "0":
+        multi_configs = {}
+        for name in ("dragon-class", "teapot-class"):
+            multi_configs[name] = run_config_sharded(name, local, rank, world, backend, in_library, by_tiles)
+
     if rank == 0:
         img = fb[0, :, :, :3]
         assert bool(torch.isfinite(img).all()) and float(img.mean()) > 0.0, "framebuffer is empty or non-finite"
@@ -391,6 +478,8 @@ def main():
         # ---- the other configurations, one full job each (N = 1 only; measured in child processes before this one started) ----
         if child_configs is not None:
             out["configs"] = child_configs
+        if multi_configs is not None:
+            out["configs"] = multi_configs
         if n_gpus == 1 and not args.no_cpu_baseline:
             from oracle import oracle  # CPU checker used here only as the reported baseline
             o = oracle.Oracle(packed)
