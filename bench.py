@@ -105,7 +105,13 @@ def pmc_per_ray(name: str):
         return None
 
 
-def rooflines(name: str, rays_per_s: float, cus: int, alg_bytes_per_ray: float | None):
+# What a wave64 VALU instruction occupies a SIMD for, by class, measured on the MI355X (selftest/valu_rate_probe, profiles/r03_valu_rates.txt):
+# add / sub / mul / mov / logic 2.4 cycles; VOP3 fma, v_pk_fma, min / max, compares, conversions, VOP3 integer operations 4.2; transcendentals 8.2
+ISSUE_CYCLES_FULL_RATE = 2.4
+ISSUE_CYCLES_HALF_RATE = 4.2
+
+
+def rooflines(name: str, rays_per_s: float, cus: int, alg_bytes_per_ray: float | None, sclk_mhz: float | None = None):
     """VALU-issue and HBM fractions of one configuration at the measured ray rate."""
     rec = pmc_per_ray(name)
     peak_lane_ops = cus * SIMDS_PER_CU * LANES_PER_SIMD_CYCLE * CLOCK_GHZ * 1e9
@@ -120,6 +126,14 @@ def rooflines(name: str, rays_per_s: float, cus: int, alg_bytes_per_ray: float |
                        "trans_lane_ops_per_ray": (rec.get("trans_wave_insts_per_ray") or 0.0) * 64.0,
                        "lanes_active": rec.get("valu_lanes_active"), "wait_any_frac": rec.get("wait_any_frac"),
                        "source": rec.get("source")}
+        # the same rate as cycles of a SIMD per VALU instruction, on the clock the kernels measured (nominal if none): `frac` above prices
+        # every instruction at 2 cycles, which no instruction class reaches (2.4 at best, 4.2 for most of what the BVH kernels execute);
+        # issue_frac_* = what fraction of a SIMD's cycles the kernel's VALU instructions occupy if all of them were full / half rate --
+        # the true occupancy lies between the two (a value above 1 says the mix cannot be all of that class)
+        clk = (sclk_mhz or CLOCK_GHZ * 1e3) * 1e6
+        cpi = cus * SIMDS_PER_CU * clk / (rays_per_s * rec["valu_wave_insts_per_ray"])
+        out["valu"].update({"issue_cycles_per_valu_inst": cpi, "issue_cycles_full_rate": ISSUE_CYCLES_FULL_RATE, "issue_cycles_half_rate": ISSUE_CYCLES_HALF_RATE,
+                            "issue_frac_if_all_full_rate": ISSUE_CYCLES_FULL_RATE / cpi, "issue_frac_if_all_half_rate": ISSUE_CYCLES_HALF_RATE / cpi})
     if rec and rec.get("hbm_read_bytes_per_ray") is not None:
         b = rec["hbm_read_bytes_per_ray"] + rec["hbm_write_bytes_per_ray"]
         out["hbm"] = {"achieved": rays_per_s * b / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -161,7 +175,7 @@ def run_config(name: str, device: int = 0):
         s2 = rr.stats()
         im = rr.download(0)
     assert bool(np.isfinite(im).all()) and float(im.mean()) > 0.0, f"{name}: image empty or non-finite"
-    rl2 = rooflines(name, s2.rays / dt, cus, bpr)
+    rl2 = rooflines(name, s2.rays / dt, cus, bpr, s2.sclk_mhz or None)
     return {"workload": lab, "width": pk.xres, "height": pk.yres, "spp": spp, "frames_per_launch": fpl,
             "triangles": api.pack_info(pk).n_triangles, "rays": s2.rays, "rays_per_path": s2.rays / max(1, s2.paths),
             "value": s2.rays / dt / 1e6, "unit": "Mrays/s", "seconds": dt, "ms_per_frame": dt / spp * 1e3,
@@ -439,7 +453,7 @@ def main():
         rate = total_rays / elapsed
         launch_ms = kernel_ms / max(1, n_launches)  # HIP events around each launch of one job, on the launch's stream
         period_ms = statistics.median(step_ms) / max(1, len(launches))
-        rl = rooflines(head, rate / n_gpus, cus, bytes_per_ray)
+        rl = rooflines(head, rate / n_gpus, cus, bytes_per_ray, sclk or None)
         rec = pmc_per_ray(head) or {}
         rays_per_launch = rays_job / max(1, n_launches)
         traffic = ((rec["hbm_read_bytes_per_ray"] + rec["hbm_write_bytes_per_ray"]) * rays_per_launch
@@ -468,12 +482,17 @@ def main():
                          "launch_period_ms": period_ms, "launches_in_flight": 1,
                          "sclk_mhz": sclk, "pmc_stale": valu.get("pmc_stale"), "kernel_source_hash": kernel_source_hash(),
                          "valu": rl["valu"], "hbm": rl["hbm"],
+                         "issue_cycles_per_valu_inst": valu.get("issue_cycles_per_valu_inst"), "issue_frac_if_all_full_rate": valu.get("issue_frac_if_all_full_rate"),
+                         "issue_frac_if_all_half_rate": valu.get("issue_frac_if_all_half_rate"),
                          "note": "the scene is cache resident: VALU issue is the roof that binds, priced at 2 cycles per wave64 "
                                  "VALU instruction on a SIMD-32 (transcendentals 4), nominal 2.4 GHz (`sclk_mhz`: what the clock was "
                                  "during the last timed job, measured by the kernel); rates are the sustained ones (rays of the timed jobs / elapsed); `launch_ms` = "
                                  "HIP events around the launch, on its stream (what rocprofv3 reports per dispatch); `useful_lane_frac` = "
                                  "frac x lanes active; `pmc_stale`: the kernel sources differ from the ones the PMC passes ran on; "
-                                 "`hbm.frac` is measured HBM traffic (PMC) against 8 TB/s"},
+                                 "`hbm.frac` is measured HBM traffic (PMC) against 8 TB/s; `issue_cycles_per_valu_inst` = SIMD cycles per VALU instruction at this rate -- "
+                                 "measured instruction costs on this chip are 2.4 (add / mul / mov / logic), 4.2 (VOP3 fma, min / max, compares, conversions) and 8.2 "
+                                 "(transcendentals) cycles, profiles/r03_valu_rates.txt: the 2-cycle peak of `frac` is not reachable, `issue_frac_if_all_full_rate` is the "
+                                 "fraction of the reachable one if every instruction were of the cheapest class"},
         }
         # ---- the other configurations, one full job each (N = 1 only; measured in child processes before this one started) ----
         if child_configs is not None:
