@@ -61,6 +61,15 @@ RENE_DEV f3 m4_point(cfloat_ptr m, f3 p) {
   return {m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12], m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
           m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14]};
 }
+// c2w . (0, 0, 0), camera.rs:79: read off the matrix.  rene_create refuses a matrix that is not finite, and for a finite one the nine
+// products by zero that m4_point(cam, 0) spells out add nothing -- but the compiler must keep them (0 * x is not 0 for every x)
+RENE_DEV f3 camera_origin(cfloat_ptr cam) {
+#ifdef RENE_CAM_ORIGIN_M4  // A/B switch: the spelled-out form
+  return m4_point(cam, f3{0.0f, 0.0f, 0.0f});
+#else
+  return f3{cam[12], cam[13], cam[14]};
+#endif
+}
 // 3x4 affine stored as x,y,z,w column vectors
 RENE_DEV f3 aff_point(const float* m, f3 p) {
   return {p.x * m[0] + p.y * m[3] + p.z * m[6] + m[9], p.x * m[1] + p.y * m[4] + p.z * m[7] + m[10],

@@ -455,6 +455,9 @@ static int rene_create_impl(const rene_scene_desc* scene, const rene_opts* opts,
   HIP_TRY(hipSetDevice(o.device));
   if (ps.width > 65535u || ps.height > 65535u)  // a lane keeps its pixel as x | y << 16
     return fail(RENE_ERR_INVALID_ARGUMENT, "resolutions above 65535 are not supported");
+  for (int i = 0; i < 16; ++i)  // the kernels read the camera's origin off the matrix instead of multiplying a zero point through it
+    if (!std::isfinite(ps.uniform.camera_to_world[i]) || !std::isfinite(ps.uniform.projection_inv[i]))
+      return fail(RENE_ERR_INVALID_ARGUMENT, "rene_uniform: camera_to_world / projection_inv must be finite");
 
   std::unique_ptr<rene_ctx> c(new rene_ctx());
   c->device = o.device;

@@ -234,3 +234,16 @@ def test_the_epoch_wraps_without_a_trace(monkeypatch, bvh):
             r.render(6 * k, 6)
         for l in range(3):
             assert np.array_equal(r.download(l), want[l])
+
+
+def test_a_camera_matrix_that_is_not_finite_is_refused():
+    # the kernels read the camera's origin off camera_to_world (c2w . (0, 0, 0), camera.rs:79) instead of multiplying a
+    # zero point through it: equal for every finite matrix, so a matrix that is not finite is an argument error
+    for field, bad in (("camera_to_world", np.nan), ("projection_inv", np.inf)):
+        s = scenes.cornell_box(16, 16)
+        m = np.array(getattr(s, field), dtype=np.float64, copy=True)
+        m[1, 2] = bad
+        setattr(s, field, m)
+        with pytest.raises(api.ReneError) as e:
+            api.Renderer(s)
+        assert e.value.code == -1 and "finite" in str(e.value)
