@@ -24,6 +24,7 @@ RENE_DEV f3 operator*(f3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
 RENE_DEV f3 operator*(float s, f3 a) { return {a.x * s, a.y * s, a.z * s}; }
 RENE_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }   // v_rcp_f32, 1 ulp
 RENE_DEV float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }   // v_rsq_f32, 1 ulp
+RENE_DEV float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); } // v_sqrt_f32, 1 ulp
 // a / b on the hot path: one v_rcp_f32 and a multiply (<= 2 ulp) instead of the ~8-instruction range-scaled quotient
 // the compiler emits for `/` (operands here are pdfs, pixel counts, cosines: far from the denormal / overflow range)
 RENE_DEV float qdiv(float a, float b) { return a * fast_rcp(b); }
@@ -31,20 +32,20 @@ RENE_DEV f3 operator/(f3 a, float s) {
   float r = fast_rcp(s);
   return {a.x * r, a.y * r, a.z * r};
 }
-RENE_DEV f3 operator/(f3 a, f3 b) { return {a.x / b.x, a.y / b.y, a.z / b.z}; }
+RENE_DEV f3 operator/(f3 a, f3 b) { return {a.x * fast_rcp(b.x), a.y * fast_rcp(b.y), a.z * fast_rcp(b.z)}; }
 RENE_DEV float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 RENE_DEV f3 cross(f3 a, f3 b) {
   return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
 RENE_DEV float length_squared(f3 a) { return dot(a, a); }
-RENE_DEV float length(f3 a) { return sqrtf(dot(a, a)); }
+RENE_DEV float length(f3 a) { return fast_sqrt(dot(a, a)); }
 RENE_DEV f3 normalize(f3 a) {
   float r = fast_rsq(dot(a, a));
   return {a.x * r, a.y * r, a.z * r};
 }
 RENE_DEV float max_element(f3 a) { return fmaxf(a.x, fmaxf(a.y, a.z)); }
 RENE_DEV bool is_zero(f3 a) { return a.x == 0.0f && a.y == 0.0f && a.z == 0.0f; }
-RENE_DEV f3 sqrt3(f3 a) { return {sqrtf(a.x), sqrtf(a.y), sqrtf(a.z)}; }
+RENE_DEV f3 sqrt3(f3 a) { return {fast_sqrt(a.x), fast_sqrt(a.y), fast_sqrt(a.z)}; }
 RENE_DEV float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }  // GLSL FClamp
 
 // column-major 4x4 (glam Mat4) times point / vector; no perspective divide (camera.rs:79-83)
