@@ -247,3 +247,26 @@ def test_a_camera_matrix_that_is_not_finite_is_refused():
         with pytest.raises(api.ReneError) as e:
             api.Renderer(s)
         assert e.value.code == -1 and "finite" in str(e.value)
+
+
+def test_image_map_repeats_over_many_periods(oracle_mod):
+    # REPEAT addressing (rene/src/main.rs:2390-2397): a quad whose uv run from -3.6 to 4.4 and from -7.3 to 2.9, so that texel
+    # indices lie within one period of the image (wrapped by an add or a subtract), several periods below it and several above
+    # (the general remainder); the first-hit albedo layer is the texture's colour at the hit, compared with the oracle's
+    rng = np.random.default_rng(5)
+    img = rng.random((5, 7, 3), dtype=np.float32)
+    for flags in (0, abi.FLAG_FORCE_BVH):
+        s = Scene.new()
+        _camera(s, 96, 64)
+        s.set_infinite_light((1.0, 1.0, 1.0))
+        m = s.add_matte(s.add_texture_image_map(img))
+        P = [-2.0, -0.5, 0.0,  2.0, -0.5, 0.0,  2.0, 1.5, 0.0,  -2.0, 1.5, 0.0]
+        UV = [-3.6, -7.3,  4.4, -7.3,  4.4, 2.9,  -3.6, 2.9]
+        s.add_triangle_mesh(TriangleMesh.from_arrays(P, [0, 1, 2, 0, 2, 3], uvs=UV), m)
+        g, o, sg, so = _both(s, 4, oracle_mod, flags)
+        assert sg["hits"] > 0.3 * sg["paths"]
+        # (the quad's uv gradient is 8 periods x 7 texels across it: a hit's barycentrics, equal to the oracle's to ~2e-5, move the look-up by
+        # ~1e-3 of a texel, i.e. ~1e-3 of the texture's contrast per frame; a wrong wrap lands on another texel: ~0.3)
+        aov_check(g[2], o[2], atol=6e-3 * 4, frac=2e-2)
+        assert abs(float(g[2].mean()) - float(o[2].mean())) <= 2e-3 * float(o[2].mean())
+        t1_check(g[0], o[0], frac=2e-2, relmse=1e-3)
