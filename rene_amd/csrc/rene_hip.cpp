@@ -1004,6 +1004,9 @@ int rene_get_stats(rene_ctx* c, rene_stats* out) {
     std::fprintf(stderr, "[rene] steps (wave executions, lanes, lanes / 64 per execution): node %llu %llu %.3f | leaf %llu %llu %.3f | logic %llu %llu %.3f | iterations %llu\n",
                  h[12], h[6], (double)h[6] / (64.0 * (double)h[12]), h[13], h[16], (double)h[16] / (64.0 * (double)std::max(1ull, h[13])), h[14], h[15],
                  (double)h[15] / (64.0 * (double)std::max(1ull, h[14])), h[17]);
+  if (std::getenv("RENE_DEBUG") && h[12] && !h[23] && h[17])  // ... and by the node step's position in its iteration: a wave's density decays from step to step
+    std::fprintf(stderr, "[rene] lanes at an inner node per iteration, at its first / second / third node step: %.3f %.3f %.3f of 64\n",
+                 (double)h[28] / (64.0 * (double)h[17]), (double)h[29] / (64.0 * (double)h[17]), (double)h[30] / (64.0 * (double)h[17]));
   if (std::getenv("RENE_DEBUG") && h[12] && !h[23])
     std::fprintf(stderr, "[rene] node visits %llu: nothing hit %llu (%.3f), reached by a pop %llu (%.3f), both %llu (%.3f); in the top levels %llu (%.3f); deepest stack %llu entries\n", h[6], h[18],
                  (double)h[18] / (double)h[6], h[19], (double)h[19] / (double)h[6], h[20], (double)h[20] / (double)h[6], h[22], (double)h[22] / (double)h[6], h[21]);
