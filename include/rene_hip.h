@@ -205,6 +205,17 @@ enum {
                                  renders any number of frames in short work items, so a job is ONE rene_render call with no tail
                                  between launches to hide, and no launch ever waits for another: the occasional stall of the
                                  two-stream scheme -- DESIGN.md section 4g -- has nothing left to come from.) */
+  ,
+  RENE_FLAG_FRAME_GROUPS = 1u << 9 /* opt-in, BVH scenes rendered by the traversal-restart kernels on an unsharded context with a framebuffer of
+                                      its own (ignored elsewhere): the frames of a rene_render call are rendered as TWO independent chains per
+                                      pixel -- the first and the second half of the call's frames, each summed in frame order into an image of
+                                      its own -- and the two images are added when the context is next drained (rene_sync, rene_download,
+                                      rene_get_stats, ...).  A pixel's frames are otherwise rendered strictly one after the other (the
+                                      reference's order of additions, rene/src/main.rs:1315-1397), and a job cannot end before its most expensive
+                                      pixel has been through all of them: rene's teapot scene at 8192 spp ends 13 % after its median wave.  Same
+                                      paths, same counters; the image equals the default one up to the rounding of the regrouped fp32 sums (as
+                                      RENE_SHARD_FRAMES does across GPUs) and is still identical from run to run, but no longer independent of
+                                      how a job is cut into rene_render calls.  n_frames of every call must be even. */
 };
 enum { RENE_SHARD_TILES = 0, RENE_SHARD_FRAMES = 1 };
 

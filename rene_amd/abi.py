@@ -24,6 +24,7 @@ LAYER_RADIANCE, LAYER_NORMAL, LAYER_ALBEDO = 0, 1, 2
 FLAG_COUNTERS, FLAG_NO_AOV, FLAG_FORCE_BVH, FLAG_SINGLE_LEVEL, FLAG_NO_RESTART, FLAG_DYNAMIC_FIRST, FLAG_WAVEFRONT = 1, 2, 4, 8, 16, 32, 64
 FLAG_OVERLAP = 128
 FLAG_FP16_PAYLOAD = 256
+FLAG_FRAME_GROUPS = 1 << 9
 FEAT_SMALL = 64  # rene_pack_info.features: the scene renders through the wave-coherent item loop (include/rene_hip.h)
 SHARD_TILES, SHARD_FRAMES = 0, 1
 

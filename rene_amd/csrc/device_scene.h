@@ -316,6 +316,10 @@ struct RenderParams {
   uint32_t prev_final;     // version the context's previous launch left on every pixel record (0: a zeroed image):
                            // what a pixel's first item continues from (launches are serial: it is there)
   float inv_n_work, inv_tiles_x;  // 1.0f / n_work, 1.0f / tiles_x (udiv_small in the work-item bookkeeping)
+  uint32_t groups_log2;    // RENE_FLAG_FRAME_GROUPS (traversal-restart kernels): a pixel's frames are rendered as 2^groups_log2 independent chains,
+                           // chain g into an image of its own (the [3][H][W][4] block g of `framebuffer`, the [H][W] block g of `item_done`);
+                           // n_work then counts every chain's slots (2^groups_log2 x owned tiles x 1024); 0: one chain, as ever
+  uint32_t group_frames;   // frames of the launch per chain (n_frames >> groups_log2; n_frames when there is one): what item_frames cuts
   unsigned long long* wave_times;  // RENE_DEBUG: [waves][2] start / end of every wave on the 100 MHz clock, else null
 };
 

@@ -66,6 +66,28 @@ hipError_t launch_pcg_probe(uint32_t seed, uint32_t n, uint32_t* out, hipStream_
   return hipGetLastError();
 }
 
+// frame groups (RenderParams.groups_log2): the chains' images added onto the first, chain by chain, and zeroed -- what a call that hands
+// the image out (rene_sync, rene_download, rene_reduce, ...) sees is one image again; 16 bytes per thread
+__global__ void __launch_bounds__(BLOCK) resolve_groups_kernel(float4* fb, size_t n4, uint32_t groups) {
+  const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n4) return;
+  float4 a = fb[i];
+  for (uint32_t g = 1; g < groups; ++g) {
+    const float4 b = fb[(size_t)g * n4 + i];
+    a.x += b.x;
+    a.y += b.y;
+    a.z += b.z;
+    fb[(size_t)g * n4 + i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  fb[i] = a;
+}
+hipError_t launch_resolve_groups(float* fb, size_t image_floats, uint32_t groups, hipStream_t st) {
+  const size_t n4 = image_floats / 4;
+  if (groups < 2 || n4 == 0) return hipSuccess;
+  hipLaunchKernelGGL(resolve_groups_kernel, dim3((unsigned)((n4 + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, reinterpret_cast<float4*>(fb), n4, groups);
+  return hipGetLastError();
+}
+
 // owned tiles <-> packed buffer (rene_gather_tiles): one thread per (owned tile, layer, texel), 16 bytes each
 __global__ void __launch_bounds__(BLOCK) pack_tiles_kernel(float* fb, float* packed, uint32_t W, uint32_t H, uint32_t tiles_x, uint32_t n_owned,
                                                             uint32_t shard_rank, uint32_t shard_count, bool unpack) {

@@ -187,6 +187,8 @@ struct rene_ctx {
   float* fb = nullptr;
   bool own_fb = false;
   size_t fb_floats = 0;
+  uint32_t groups_log2 = 0;     // RENE_FLAG_FRAME_GROUPS: every pixel's frames as 2^groups_log2 chains, each into an image of its own behind `fb`;
+                                // drain() adds the chains' images onto the first and zeroes them (resolve_groups)
   static constexpr uint32_t kCounters = 60;  // launches between two drains: each takes its own zeroed work counter
   uint32_t* d_work_counters = nullptr;        // [kCounters]
   unsigned long long* d_wave_times = nullptr; // RENE_DEBUG: [kCounters][8192][2]
@@ -369,6 +371,11 @@ struct rene_ctx {
                          std::to_string(t[2] >> 32) + ", wanted version " + std::to_string(t[3]) + ", saw " + std::to_string(t[2] & 0xffffffffu) + "]";
     }
     if (handoff_failed) return fail(RENE_ERR_DEVICE, "work items were dropped inside the render kernel and replaying their launches did not complete them (results invalid; rene_reset clears the condition)" + handoff_detail);
+    if (groups_log2 && had_launches) {  // frame groups: the chains' images onto the first (the stream is idle; the next launch's chains start from zero sums)
+      hipError_t e = rene::launch_resolve_groups(fb, fb_floats, 1u << groups_log2, stream);
+      if (e != hipSuccess) return fail(RENE_ERR_DEVICE, std::string("resolve_groups: ") + hipGetErrorString(e));
+      HIP_TRY(wait_stream(stream));
+    }
     return RENE_OK;
   }
 };
@@ -592,10 +599,17 @@ static int rene_create_impl(const rene_scene_desc* scene, const rene_opts* opts,
   }
 
   c->fb_floats = (size_t)3 * ps.width * ps.height * 4;
+  // Frame groups: only where the traversal-restart kernels render (render_wf.inc implements the chains), into a framebuffer of the
+  // context's own (a caller's is one image), on an unsharded context; everything else renders one chain as ever.
+  if ((o.flags & RENE_FLAG_FRAME_GROUPS) && !o.framebuffer && o.shard_count <= 1 && !(o.flags & (RENE_FLAG_NO_RESTART | RENE_FLAG_WAVEFRONT)) &&
+      !(c->cfg.features & (rene::FEAT_SMALL | rene::FEAT_VOLPATH)) && ps.main.nodes.size() > 512) {
+    c->groups_log2 = 1;
+    if (const char* e = std::getenv("RENE_FRAME_GROUPS")) c->groups_log2 = std::atoi(e) >= 4 ? 2u : std::atoi(e) >= 2 ? 1u : 0u;  // tuning knob: 1, 2 or 4 chains
+  }
   if (o.framebuffer) {
     c->fb = static_cast<float*>(o.framebuffer);
   } else {
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->fb), c->fb_floats * sizeof(float)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->fb), (c->fb_floats << c->groups_log2) * sizeof(float)));
     c->own_fb = true;
   }
   // Which integrator renders this scene: the item-loop megakernel (small scenes), the volpath megakernel,
@@ -634,9 +648,9 @@ static int rene_create_impl(const rene_scene_desc* scene, const rene_opts* opts,
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_work_counters), rene_ctx::kCounters * sizeof(uint32_t)));
   HIP_TRY(hipMemsetAsync(c->d_work_counters, 0, rene_ctx::kCounters * sizeof(uint32_t), c->stream));
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_counters), 32 * sizeof(unsigned long long)));
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_item_done), (size_t)ps.width * ps.height * sizeof(uint32_t)));  // one version word per pixel
-  HIP_TRY(hipMemsetAsync(c->d_item_done, 0, (size_t)ps.width * ps.height * sizeof(uint32_t), c->stream));
-  HIP_TRY(hipMemsetAsync(c->fb, 0, c->fb_floats * sizeof(float), c->stream));  // main.rs:1229-1237
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_item_done), ((size_t)ps.width * ps.height << c->groups_log2) * sizeof(uint32_t)));  // one version word per pixel (and chain)
+  HIP_TRY(hipMemsetAsync(c->d_item_done, 0, ((size_t)ps.width * ps.height << c->groups_log2) * sizeof(uint32_t), c->stream));
+  HIP_TRY(hipMemsetAsync(c->fb, 0, (c->fb_floats << (c->own_fb ? c->groups_log2 : 0u)) * sizeof(float), c->stream));  // main.rs:1229-1237
   HIP_TRY(hipMemsetAsync(c->d_counters, 0, 32 * sizeof(unsigned long long), c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   HIP_TRY(hipDeviceSynchronize());  // everything the uploads left on the null stream (the fills of empty tables) has run: see zero_now
@@ -700,6 +714,8 @@ static int rene_render_impl(rene_ctx* c, uint32_t first_frame, uint32_t n_frames
     my_stride = n;
     my_count = skip < n_frames ? (n_frames - skip + n - 1) / n : 0;
   }
+  if (c->groups_log2 && (my_count & ((1u << c->groups_log2) - 1u)))
+    return fail(RENE_ERR_INVALID_ARGUMENT, "RENE_FLAG_FRAME_GROUPS: the frames of a rene_render call must be a multiple of the number of chains (2)");
   c->frames += n_frames;
   if (my_count == 0 || c->n_work == 0) return RENE_OK;
   c->paths += (uint64_t)my_count * c->owned_pixels;
@@ -740,11 +756,13 @@ static int rene_render_impl(rene_ctx* c, uint32_t first_frame, uint32_t n_frames
   P.item_done = c->d_item_done;
   P.counters = c->d_counters;
   P.n_frames = my_count;
-  P.n_work = c->n_work;
+  P.n_work = c->n_work << c->groups_log2;  // (a level's work ids: the slots of chain 0, then those of chain 1, ...)
+  P.groups_log2 = c->groups_log2;
+  P.group_frames = my_count >> c->groups_log2;
   P.shard_rank = c->opts.shard_mode == RENE_SHARD_TILES ? c->opts.shard_rank : 0;
   P.shard_count = c->opts.shard_mode == RENE_SHARD_TILES ? c->opts.shard_count : 1;
   P.tiles_x = c->tiles_x;
-  P.inv_n_work = 1.0f / (float)std::max(1u, c->n_work);
+  P.inv_n_work = 1.0f / (float)std::max(1u, P.n_work);
   P.inv_tiles_x = 1.0f / (float)std::max(1u, c->tiles_x);
   P.n_tiles = c->n_tiles;
   P.flags = c->opts.flags;
@@ -760,7 +778,7 @@ static int rene_render_impl(rene_ctx* c, uint32_t first_frame, uint32_t n_frames
   // every pixel's frames in work items (device_code.inc, item_frames): uniform items of `item` frames, the last one or two of
   // them cut into halving items down to `tail` frames; RENE_LEVELS=<n> (tests, A/B measurements) cuts into n uniform items
   {
-    const uint32_t F = P.n_frames;
+    const uint32_t F = P.group_frames;  // (what the items cut: the frames of one chain)
     // untuned: sixteen items per pixel and launch for the item-loop kernels, 32 for the BVH kernels, at least 16 frames each
     // (measured, one launch per job, MI355X: Cornell 1024 frames flat from 64 to 96 frames per item, veach-mis 4096 frames best at
     // 256 - 341, dragon-class 1024 at 32, the teapot scene 8192 at 256: it is the number of item switches per pixel that a launch
@@ -768,7 +786,9 @@ static int rene_render_impl(rene_ctx* c, uint32_t first_frame, uint32_t n_frames
     // no halving tail by default (tail = item): it buys nothing once the hand-off waits are rare
     // (short launches -- one rank's share of a multi-GPU job -- want few, long items: Cornell 128 frames, 8 / 16 / 32 / 64 frames per
     // item: 6.89 / 6.59 / 6.59 / 6.41 ms; 256 frames, 16 / 32 / 64 / 128: 13.30 / 13.13 / 13.21 / 12.84; 512 frames, 32 / 64 / 128: 24.93 / 24.74 / 25.23)
-    uint32_t item = c->item_frames ? c->item_frames : ((c->cfg.features & rene::FEAT_SMALL) ? std::max(64u, F / 16u) : std::max(16u, F / 32u));
+    // (frame groups: a chain has half the frames and wants items as long as the undivided job's, or longer -- dragon-class, two chains of 512
+    // frames: items of 16 / 32 / 64 frames 671 / 653 / 642 ms; the teapot scene, two chains of 4096: 128 / 256 / 512 / 1024 frames 3139 / 3106 / 3179 / 3157 ms)
+    uint32_t item = c->item_frames ? c->item_frames : ((c->cfg.features & rene::FEAT_SMALL) ? std::max(64u, F / 16u) : std::max(16u, c->groups_log2 ? F / 16u : F / 32u));
     uint32_t tail = item;
     if (const char* e = std::getenv("RENE_ITEM_FRAMES")) item = (uint32_t)std::max(1, std::atoi(e));  // tuning knobs
     if (const char* e = std::getenv("RENE_ITEM_TAIL")) tail = (uint32_t)std::max(1, std::atoi(e));
@@ -779,7 +799,7 @@ static int rene_render_impl(rene_ctx* c, uint32_t first_frame, uint32_t n_frames
     }
     if (c->item_frames == rene_ctx::kWholeLaunch || (c->opts.flags & RENE_FLAG_SINGLE_LEVEL) || F < 4) item = tail = F;
     // work ids are 32-bit (level * n_work + slot < 2^31) and a version counts at most MAX_LEVELS items
-    const uint32_t max_levels = std::max(1u, std::min(rene::MAX_LEVELS, (uint32_t)(0x7fffffffu / std::max(1u, c->n_work))));
+    const uint32_t max_levels = std::max(1u, std::min(rene::MAX_LEVELS, (uint32_t)(0x7fffffffu / std::max(1u, P.n_work))));
     item = std::min(std::max(item, 1u), F);
     for (;;) {
       uint32_t K = F / item, R = F - K * item, H = R ? 1u : 0u;  // K uniform items, then H halving items over the rest R
@@ -806,7 +826,7 @@ static int rene_render_impl(rene_ctx* c, uint32_t first_frame, uint32_t n_frames
   P.prev_final = c->prev_final;
   if (c->epoch >= rene::MAX_EPOCH) {  // (drained above) the epoch wraps: every pixel record back to version 0
     hipMemset2DAsync(c->fb + 3, 4 * sizeof(float), 0, sizeof(float), c->fb_floats / 4, stream);
-    hipMemsetAsync(c->d_item_done, 0, (size_t)c->width * c->height * sizeof(uint32_t), stream);
+    hipMemsetAsync(c->d_item_done, 0, ((size_t)c->width * c->height << c->groups_log2) * sizeof(uint32_t), stream);
     c->epoch = 0;
     P.prev_final = 0;
   }
@@ -853,7 +873,7 @@ static int rene_render_impl(rene_ctx* c, uint32_t first_frame, uint32_t n_frames
   rene::LaunchConfig cfg = c->cfg;
   // launch no more lanes than there are work items; hand items out in batches small enough that every
   // launched wave gets some (a tile shard of a small image has fewer items than the chip has lanes)
-  const uint32_t total_items = P.n_levels * c->n_work;
+  const uint32_t total_items = P.n_levels * P.n_work;
   uint32_t blocks_needed = (total_items + rene::render_block_size() - 1) / rene::render_block_size();
   cfg.grid = std::max(1u, std::min(cfg.grid, blocks_needed));
   const uint32_t waves = cfg.grid * (uint32_t)(rene::render_block_size() / 64);
@@ -902,9 +922,9 @@ int rene_reset(rene_ctx* c) {
   if (rc != RENE_OK && !c->handoff_failed) return rc;
   c->handoff_failed = false;  // the counters are cleared below and the image starts again from zero
   c->exchanged = false;
-  HIP_TRY(hipMemsetAsync(c->fb, 0, c->fb_floats * sizeof(float), c->stream));
+  HIP_TRY(hipMemsetAsync(c->fb, 0, (c->fb_floats << (c->own_fb ? c->groups_log2 : 0u)) * sizeof(float), c->stream));
   HIP_TRY(hipMemsetAsync(c->d_counters, 0, 32 * sizeof(unsigned long long), c->stream));
-  HIP_TRY(hipMemsetAsync(c->d_item_done, 0, (size_t)c->width * c->height * sizeof(uint32_t), c->stream));
+  HIP_TRY(hipMemsetAsync(c->d_item_done, 0, ((size_t)c->width * c->height << c->groups_log2) * sizeof(uint32_t), c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->prev_final = 0;  // the pixel records carry version 0 again
   c->frames = 0;

@@ -411,3 +411,38 @@ def test_soak_many_launches_none_replayed():
                 else:
                     assert np.array_equal(img, first), j
     assert np.isfinite(first).all() and first.sum() > 0
+
+
+@pytest.mark.parametrize("name", ["dragon", "teapot"])
+def test_frame_groups_render_the_same_paths_into_two_chains(name):
+    """RENE_FLAG_FRAME_GROUPS (include/rene_hip.h): the frames of a call as two independent chains per pixel, added when the context
+    is drained.  The paths are the default's (identical counters), the image the default's up to the rounding of the regrouped sums,
+    identical from run to run, over several calls and on top of an earlier sync; calls with an odd number of frames are refused,
+    and where the flag does not apply (small scenes) it changes nothing."""
+    s = {"dragon": lambda: scenes.dragon_class(160, 90, 40, 44), "teapot": lambda: scenes.teapot_class(128, 72, 40, 44)}[name]()
+    assert api.pack_info(s).n_nodes_main > 512  # (shallower trees are rendered by the while-while kernel, where the flag does not apply)
+    keys = ("rays_closest", "rays_shadow", "rays_emitter", "paths", "hits", "adds")
+    with api.Renderer(s) as r:
+        r.render(0, 24)
+        r.render(24, 8)
+        ref = [r.download(k) for k in range(3)]
+        sr = r.stats().as_dict()
+    runs = []
+    for _ in range(2):
+        with api.Renderer(s, flags=abi.FLAG_FRAME_GROUPS) as g:
+            g.render(0, 24)
+            g.sync()  # (the chains are added here, and the next call's start again from zero)
+            g.render(24, 8)
+            runs.append([g.download(k) for k in range(3)])
+            sg = g.stats().as_dict()
+            with pytest.raises(api.ReneError):
+                g.render(32, 3)
+    assert {k: sg[k] for k in keys} == {k: sr[k] for k in keys}
+    for k in range(3):
+        np.testing.assert_array_equal(runs[0][k], runs[1][k])
+        np.testing.assert_allclose(runs[0][k], ref[k], rtol=2e-6, atol=1e-6 * 32)
+    small = scenes.cornell_box(32, 32)
+    with api.Renderer(small) as a, api.Renderer(small, flags=abi.FLAG_FRAME_GROUPS) as b:
+        a.render(0, 5)
+        b.render(0, 5)
+        np.testing.assert_array_equal(a.download(0), b.download(0))
