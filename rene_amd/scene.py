@@ -95,6 +95,11 @@ class Scene:
         return self._push_texture(t)
 
     def add_texture_image_map(self, image: np.ndarray) -> int:
+        image = np.asarray(image, dtype=F32)
+        if image.ndim != 3 or image.shape[2] not in (3, 4):
+            raise ValueError(f"an image is (h, w, 4) RGBA (or (h, w, 3), padded here): got {image.shape}")
+        if image.shape[2] == 3:  # (the C ABI's rene_image is RGBA: four floats per texel)
+            image = np.concatenate([image, np.ones(image.shape[:2] + (1,), dtype=F32)], axis=2)
         self.images.append(np.ascontiguousarray(image, dtype=F32))
         t = abi.Texture(type=abi.TEXTURE_IMAGEMAP)
         t.u0[:] = [len(self.images) - 1, 0, 0, 0]

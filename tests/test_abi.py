@@ -223,3 +223,18 @@ def test_missing_rccl_is_an_error_code_not_a_crash():
     p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
     assert p.returncode == 0, p.stderr[-500:]
     assert "CODE -4" in p.stdout and "RCCL is not available" in p.stdout and "librccl-absent" in p.stdout, p.stdout
+
+
+def test_image_maps_are_rgba_and_rgb_is_padded():
+    # rene_image is four floats per texel (include/rene_hip.h): an (h, w, 3) array handed to the scene builder is padded,
+    # anything else is refused (it used to be passed on as it was, and the packer read past its end)
+    import numpy as np
+    from rene_amd.scene import Scene
+    s = Scene.new()
+    t = s.add_texture_image_map(np.full((5, 7, 3), 0.25, dtype=np.float32))
+    assert s.images[-1].shape == (5, 7, 4) and (s.images[-1][..., 3] == 1).all() and (s.images[-1][..., :3] == 0.25).all()
+    s.add_texture_image_map(np.zeros((2, 2, 4), dtype=np.float32))
+    for bad in (np.zeros((4, 4)), np.zeros((4, 4, 2)), np.zeros((4,))):
+        with pytest.raises(ValueError):
+            s.add_texture_image_map(bad)
+    assert t >= 0
