@@ -2,7 +2,7 @@
 //
 //   rene-hip <scene.pbrt> [--aov-normal PATH] [--aov-albedo PATH] [--denoiser none|optix|oidn]
 //            [--dump-module PATH]                       <- the reference's five options (main.rs:54-71)
-//            [--spp N] [--seed S] [--width W] [--height H] [--gpus G] [--batch B] [--out PATH]
+//            [--spp N] [--seed S] [--width W] [--height H] [--gpus G] [--batch B] [--out PATH] [--frame-groups]
 //
 // The reference hard-codes 5000 samples in batches of 100 (main.rs:80-81); --spp / --batch default
 // to those.  Output name = Film "filename" (+ ".png" when it ends in ".exr", main.rs:1651-1656).
@@ -94,7 +94,7 @@ void usage() {
   std::fprintf(stderr,
                "usage: rene-hip <pbrt file> [--aov-normal PATH] [--aov-albedo PATH] [--denoiser none|optix|oidn]\n"
                "                [--dump-module PATH] [--spp N] [--seed S] [--width W] [--height H] [--gpus G]\n"
-               "                [--batch B] [--out PATH]\n");
+               "                [--batch B] [--out PATH] [--frame-groups]\n");
 }
 
 }  // namespace
@@ -103,6 +103,7 @@ int main(int argc, char** argv) {
   auto t_start = std::chrono::steady_clock::now();
   std::string pbrt_path, aov_normal, aov_albedo, denoiser = "none", dump_module, out_override;
   uint32_t spp = 5000, batch = 100, seed = RENE_DEFAULT_SEED, width = 0, height = 0, gpus = 1;
+  bool frame_groups = false;  // RENE_FLAG_FRAME_GROUPS: every batch's frames as two chains per pixel (additive; one GPU, BVH scenes)
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
     auto val = [&](const char* name) -> const char* {
@@ -123,6 +124,7 @@ int main(int argc, char** argv) {
     else if (a == "--height") height = (uint32_t)std::strtoul(val("--height"), nullptr, 0);
     else if (a == "--gpus") gpus = (uint32_t)std::strtoul(val("--gpus"), nullptr, 0);
     else if (a == "--out") out_override = val("--out");
+    else if (a == "--frame-groups") frame_groups = true;
     else if (a == "-h" || a == "--help") { usage(); return 0; }
     else if (!a.empty() && a[0] == '-') { std::fprintf(stderr, "rene-hip: unknown option %s\n", a.c_str()); usage(); return 2; }
     else pbrt_path = a;
@@ -149,6 +151,10 @@ int main(int argc, char** argv) {
     return 0;
   }
   if (pbrt_path.empty() || spp == 0 || batch == 0 || gpus == 0) { usage(); return 2; }
+  if (frame_groups) {  // two chains per pixel want an even number of frames per rene_render call
+    if (spp & 1u) { std::fprintf(stderr, "rene-hip: --frame-groups needs an even --spp\n"); return 2; }
+    batch = std::max(2u, batch & ~1u);
+  }
 
   rene_scene* scene = nullptr;
   if (rene_scene_load_pbrt(pbrt_path.c_str(), &scene) != RENE_OK) {
@@ -180,6 +186,7 @@ int main(int argc, char** argv) {
     o.shard_mode = RENE_SHARD_TILES;
     o.shard_rank = g;
     o.shard_count = gpus;
+    if (frame_groups && gpus == 1) o.flags |= RENE_FLAG_FRAME_GROUPS;
     // all three layers are accumulated whether or not --aov-* asks for the files, like the reference's raygen
     // (lib.rs:229-232); RENE_FLAG_NO_AOV would save little and its Matte item-loop kernel happens to be the slower one
     if (rene_create(&desc, &o, &ctx[g]) != RENE_OK) return die("rene_create");
