@@ -334,3 +334,26 @@ def test_dropped_work_items_are_replayed_bit_identically(monkeypatch, name):
         for k in ("rays_closest", "rays_shadow", "rays_emitter", "hits", "adds", "paths"):
             assert sg[k] == sw[k], (name, launch, k, sg[k], sw[k])
         assert sg["launches"] > sw["launches"], "the injected drop must have caused a replay"
+
+
+def test_dropped_work_items_are_replayed_with_two_chains_per_pixel(monkeypatch):
+    """The same under RENE_FLAG_FRAME_GROUPS (two chains of frames per pixel inside every launch, added at the sync): a replayed
+    launch finds what either chain committed the first time and skips it."""
+    s = scenes.dragon_class(160, 90, 40, 44)
+    def job(r):
+        for f0 in range(0, 24, 6):
+            r.render(f0, 6)
+        r.sync()
+        return [r.download(l) for l in range(3)], r.stats().as_dict()
+    monkeypatch.delenv("RENE_TEST_DROP", raising=False)
+    with api.Renderer(s, flags=abi.FLAG_FRAME_GROUPS) as r:
+        want, sw = job(r)
+    for launch in (1, 3):
+        monkeypatch.setenv("RENE_TEST_DROP", str(launch))
+        with api.Renderer(s, flags=abi.FLAG_FRAME_GROUPS) as r:
+            got, sg = job(r)
+        for a, b in zip(want, got):
+            assert np.array_equal(a, b), launch
+        for k in ("rays_closest", "rays_shadow", "rays_emitter", "hits", "adds", "paths"):
+            assert sg[k] == sw[k], (launch, k, sg[k], sw[k])
+        assert sg["launches"] > sw["launches"], "the injected drop must have caused a replay"

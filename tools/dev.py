@@ -91,15 +91,19 @@ def main():
         from rene_amd import api, scenes
         for nm, s, spp in (("dragon-class 1920x1080 @ 1024 spp", scenes.dragon_class(1920, 1080), 1024),
                            ("teapot-full 1920x1080 @ 8192 spp", scenes.teapot_full(1920, 1080), 8192)):
-            with api.Renderer(s) as r:
-                t0 = time.perf_counter()
-                r.render(0, spp)  # one launch per job
-                r.sync()
-                dt = time.perf_counter() - t0
-                st = r.stats()  # raises if a hand-off timed out and its replay did not repair it
-                img = r.download(0)
-            print(f"{nm}: {dt:.2f} s, {st.rays / dt / 1e6:.0f} Mrays/s, {dt * 1e3 / spp:.3f} ms/frame, launches {st.launches} (1 = none replayed), "
-                  f"finite {bool(np.isfinite(img).all())}, mean {img.mean() / spp:.4f}", flush=True)
+            with api.Renderer(s, flags=a.flags) as r:  # (--flags 0x200: RENE_FLAG_FRAME_GROUPS, two chains of frames per pixel)
+                first = None
+                for j in range(max(1, a.launches // 6)):  # --launches 6 (the default): one job; 60: ten
+                    r.reset()
+                    t0 = time.perf_counter()
+                    r.render(0, spp)  # one launch per job
+                    r.sync()
+                    dt = time.perf_counter() - t0
+                    st = r.stats()  # raises if a hand-off timed out and its replay did not repair it
+                    img = r.download(0)
+                    first = img if first is None else first
+                    print(f"{nm}: job {j}: {dt:.2f} s, {st.rays / dt / 1e6:.0f} Mrays/s, {dt * 1e3 / spp:.3f} ms/frame, launches {st.launches} (1 = none replayed), "
+                          f"finite {bool(np.isfinite(img).all())}, mean {img.mean() / spp:.4f}, equal to the first job's image: {bool(np.array_equal(img, first))}", flush=True)
     elif a.command == "counters":
         from rene_amd import abi, api
         tab = scene_table()
