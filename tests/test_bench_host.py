@@ -60,3 +60,18 @@ def test_a_failing_or_stalling_configuration_becomes_an_error_entry(monkeypatch,
     assert "exit code 3" in out["dragon-class"]["error"] and "boom" in out["dragon-class"]["stderr_tail"]
     assert "did not finish" in out["teapot-class"]["error"] and "did not finish" in out["dragon-partial"]["error"] and "did not finish" in out["material-zoo"]["error"]
     json.dumps(out)
+
+
+def test_the_committed_bench_line_times_the_bvh_jobs_both_ways():
+    """bench.py's `configs`: the BVH configurations in the reference's strict frame order AND as two chains of frames per pixel
+    (RENE_FLAG_FRAME_GROUPS; `value` is the latter, `strict_order` the former, with how far the two images are apart); the
+    small scenes have no such tail and run one chain."""
+    import glob
+    path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_bench.json")))[-1]
+    d = json.loads(open(path).read().strip().splitlines()[-1])
+    assert d["roofline"]["pmc_stale"] is False, path
+    for name in ("dragon-class", "teapot-class", "dragon-partial"):
+        c = d["configs"][name]
+        assert c["frame_groups"] == 2 and c["strict_order"]["value"] > 0 and c["strict_order"]["max_rel_image_difference"] <= 1e-3, name
+    for name in ("veach-mis", "material-zoo"):
+        assert d["configs"][name]["frame_groups"] == 1 and d["configs"][name]["strict_order"] is None
