@@ -602,7 +602,7 @@ static int rene_create_impl(const rene_scene_desc* scene, const rene_opts* opts,
   // Frame groups: only where the traversal-restart kernels render (render_wf.inc implements the chains), into a framebuffer of the
   // context's own (a caller's is one image), on an unsharded context; everything else renders one chain as ever.
   if ((o.flags & RENE_FLAG_FRAME_GROUPS) && !o.framebuffer && o.shard_count <= 1 && !(o.flags & (RENE_FLAG_NO_RESTART | RENE_FLAG_WAVEFRONT)) &&
-      !(c->cfg.features & (rene::FEAT_SMALL | rene::FEAT_VOLPATH)) && ps.main.nodes.size() > 512) {
+      !(c->cfg.features & rene::FEAT_SMALL) && ps.main.nodes.size() > 512) {  // (both integrators: kernels_bvh.hip and kernels_vol.hip pick the restart kernel by the same rule)
     c->groups_log2 = 1;
     if (const char* e = std::getenv("RENE_FRAME_GROUPS")) c->groups_log2 = std::atoi(e) >= 4 ? 2u : std::atoi(e) >= 2 ? 1u : 0u;  // tuning knob: 1, 2 or 4 chains
   }

@@ -413,13 +413,14 @@ def test_soak_many_launches_none_replayed():
     assert np.isfinite(first).all() and first.sum() > 0
 
 
-@pytest.mark.parametrize("name", ["dragon", "teapot"])
+@pytest.mark.parametrize("name", ["dragon", "teapot", "fog"])
 def test_frame_groups_render_the_same_paths_into_two_chains(name):
     """RENE_FLAG_FRAME_GROUPS (include/rene_hip.h): the frames of a call as two independent chains per pixel, added when the context
     is drained.  The paths are the default's (identical counters), the image the default's up to the rounding of the regrouped sums,
     identical from run to run, over several calls and on top of an earlier sync; calls with an odd number of frames are refused,
     and where the flag does not apply (small scenes) it changes nothing."""
-    s = {"dragon": lambda: scenes.dragon_class(160, 90, 40, 44), "teapot": lambda: scenes.teapot_class(128, 72, 40, 44)}[name]()
+    s = {"dragon": lambda: scenes.dragon_class(160, 90, 40, 44), "teapot": lambda: scenes.teapot_class(128, 72, 40, 44),
+         "fog": lambda: scenes.dragon_fog(128, 72, 40, 44)}[name]()  # (fog: Integrator "volpath", the restart kernel of kernels_vol.hip)
     assert api.pack_info(s).n_nodes_main > 512  # (shallower trees are rendered by the while-while kernel, where the flag does not apply)
     keys = ("rays_closest", "rays_shadow", "rays_emitter", "paths", "hits", "adds")
     with api.Renderer(s) as r:
