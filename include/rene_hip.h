@@ -215,7 +215,8 @@ enum {
                                       pixel has been through all of them: rene's teapot scene at 8192 spp ends 13 % after its median wave.  Same
                                       paths, same counters; the image equals the default one up to the rounding of the regrouped fp32 sums (as
                                       RENE_SHARD_FRAMES does across GPUs) and is still identical from run to run, but no longer independent of
-                                      how a job is cut into rene_render calls.  n_frames of every call must be even. */
+                                      how a job is cut into rene_render calls.  n_frames of every call must be even; rene_framebuffer waits for the launches
+                                      (the image is one image only once the chains have been added). */
 };
 enum { RENE_SHARD_TILES = 0, RENE_SHARD_FRAMES = 1 };
 

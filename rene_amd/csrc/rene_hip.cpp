@@ -977,6 +977,10 @@ int rene_framebuffer(rene_ctx* c, void** device_ptr, size_t* n_floats) {
   *device_ptr = c->fb;
   if (n_floats) *n_floats = c->fb_floats;
   HIP_TRY(hipSetDevice(c->device));
+  if (c->groups_log2) {  // frame groups: the image is one image only after the chains have been added (drain), not in stream order
+    int rc = c->drain();
+    if (rc != RENE_OK) return rc;
+  }
   return c->flush_exchange();
 }
 
