@@ -5,7 +5,8 @@
         (plus zoo, fog, media-zoo, dragon-fog, veach-bvh, cornell-bvh), launches one after the other
   sweep VAR V1,V2,... NAME [rate options]                           the same once per value of an environment knob
         (RENE_LEVELS, RENE_READY_MIN, RENE_LEAF_MIN, RENE_BLOCKS_PER_CU, ...): fresh process per value
-  soak                                                               C4 / C5 at their full sample counts: no hand-off may time out
+  soak [--flags 0x200] [--launches 6 x jobs]                         C4 / C5 at their full sample counts, one launch per job: no hand-off may time out,
+        every job's image equal to the first one's (0x200: RENE_FLAG_FRAME_GROUPS)
   counters NAME...                                                   per-ray node / primitive / hit counters of the counting pass
 """
 import argparse
