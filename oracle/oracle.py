@@ -57,6 +57,9 @@ def lib():
         L.oracle_roughness_to_alpha.argtypes = [C.c_float, C.c_void_p]
         L.oracle_tex_color.argtypes = [C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_void_p]
         L.oracle_scene_info.argtypes = [C.c_void_p, C.c_void_p]
+        L.oracle_set_experiment.argtypes = [C.c_void_p, C.c_uint32, C.c_int]
+        L.oracle_set_experiment.restype = None
+        L.oracle_download_decomposition.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -101,6 +104,20 @@ class Oracle:
         st = abi.Stats()
         lib().oracle_get_stats(self._h, C.byref(st))
         return st
+
+    # one-statement departures from the restatement (Scene::X_* in rene_oracle.cpp; tools/cornell_offsets.py), all off by default
+    X = {"pdf_wo_wi": 1 << 0, "pdfl_occluded": 1 << 1, "no_primcount": 1 << 2, "rr_from_3": 1 << 3, "rr_off": 1 << 4, "rr_clamp": 1 << 5,
+         "emit_two_sided": 1 << 6, "tie_last": 1 << 7, "pos_from_ray": 1 << 8, "pdfl_front_only": 1 << 9, "pixel_rng": 1 << 10,
+         "jitter_w": 1 << 11, "light_pdf_area": 1 << 12, "tmin_1e4": 1 << 13, "cos_from_ng": 1 << 14, "pdf_faceforward": 1 << 15,
+         "pdf_zero": 1 << 16}
+
+    def set_experiment(self, bits: int = 0, decomposition: bool = False, depth_cap: int = 0):
+        lib().oracle_set_experiment(self._h, (bits | (depth_cap << 24)) & 0xFFFFFFFF, int(decomposition))
+
+    def download_decomposition(self, depth: int, branch: int) -> np.ndarray:
+        out = np.empty((self.yres, self.xres, 3), dtype=np.float32)
+        assert lib().oracle_download_decomposition(self._h, depth, branch, _p(out)) == 0
+        return out
 
     def trace(self, origins, directions, tmin=0.001, tmax=1e5, which=0, bruteforce=False) -> np.ndarray:
         o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)

@@ -46,81 +46,91 @@ def test_t2_veach_mis_vs_renes_render():
     assert rmse < 0.009 and abs(ratio - 1) < 0.012  # measured 0.00716 (x 1.25) / 0.9919; rene vs Tungsten: 0.174
 
 
-# ---- rene's own sample count, 4 x 4 boxes, and the energy of every surface -----------------------------
-def _t2_regions(name, scene, oracle_mod, spp=5000):
+# ---- rene's own sample count, 4 x 4 boxes, and the energy of every surface ---------------------
+T2_SEEDS = (0x52454E45, 0x9E3779B9, 0x3C6EF372, 0xDAA66D2B)  # the build's default master seed and three more (tools/t2_dump.py's)
+
+
+def _t2_regions(name, scene, oracle_mod, spp=5000, seeds=T2_SEEDS):
+    """(4 x 4 box sRGB RMSE of the first seed's image, rows) -- rows: (instance, quad, cells, rene's mean linear rgb, per-seed ratios [seeds][3])."""
     import t2_regions as T
     srgb4, lin4 = T.rene_box4(name)
-    with api.Renderer(scene) as r:
-        r.render(0, spp)
-        rgb8 = api.to_rgb8(r.download(0), spp)
-    mine4 = T.box(rgb8.astype(np.float32) / 255.0, 4)
-    rmse = float(np.sqrt(((mine4 - srgb4) ** 2).mean()))
     reg = T.region_map(oracle_mod, scene, 4)
-    mine_lin4 = T.box(T.to_linear(rgb8.astype(np.float32) / 255.0), 4)
+    rmse, per_seed = None, []
+    for seed in seeds:
+        with api.Renderer(scene, seed=seed) as r:
+            r.render(0, spp)
+            rgb8 = api.to_rgb8(r.download(0), spp)
+        if rmse is None:
+            rmse = float(np.sqrt(((T.box(rgb8.astype(np.float32) / 255.0, 4) - srgb4) ** 2).mean()))
+        per_seed.append(T.box(T.to_linear(rgb8.astype(np.float32) / 255.0), 4))
     rows = []
     for rid in np.unique(reg):
         m = reg == rid
         if rid < 0 or m.sum() < 150:
             continue
-        a, b = mine_lin4[m].mean(axis=0), lin4[m].mean(axis=0)
-        rows.append((int(rid) >> 12, int(rid) & 4095, int(m.sum()), b, a / np.maximum(b, 1e-9)))
+        b = lin4[m].mean(axis=0)
+        rows.append((int(rid) >> 12, int(rid) & 4095, int(m.sum()), b, np.array([x[m].mean(axis=0) / np.maximum(b, 1e-9) for x in per_seed])))
     return rmse, rows
 
 
 def _show(rows):
-    return "\n".join(f"  instance {i} quad {q}: {c} cells, rene linear {np.round(b, 4)}, ratio {np.round(r, 4)}" for i, q, c, b, r in rows)
+    return "\n".join(f"  instance {i} quad {q}: {c} cells, rene linear {np.round(b, 4)}, ratio mean over seeds {np.round(r.mean(axis=0), 4)}, "
+                     f"spread over seeds {np.round(r.max(axis=0) - r.min(axis=0), 4)}" for i, q, c, b, r in rows)
 
 
-# Measured on the MI355X in round 3 (5000 frames, fixed seed schedule: reproducible): mean linear radiance of the region here /
-# in rene's PNG, per channel, for the channels rene's 8 bits resolve (mean linear in [0.03, 0.9): a quantisation step is then
-# below 3 % and the image's own noise dithers it).  (instance, quad) -> ratios.  The build is 1 - 4 % brighter than rene's
-# published Cornell on the walls and the floor and 6.4 % on the ceiling (instance 1; there the ratio also varies over the
-# surface, 0.95 near the light to 1.06 away from it) -- offsets of the published image, whose code version is unknown (the
-# checkout has no history); the ORACLE shows the same offsets (tests/test_oracle_render.py), so they are not the HIP path's.
-# The test pins every ratio to +- 1 %: a one-per-cent change of the energy of any one surface fails it.
+# Round 4 (profiles/r04_cornell_offsets.txt).  Quirk Q3 -- ONE light / BSDF coin per frame -- makes the energy a 5000-frame image holds at
+# bounce d proportional to the number of its frames whose first light-branch coin falls at bounce d - 1 (binomial: +- 1.4 % at d = 1, 2.4 %,
+# 3.7 %, 5.5 % ...), so ONE render's region energies scatter by up to 2.4 % between master seeds (rene's published image is one such draw, from
+# entropy seeds).  Round 3 pinned the default seed's ratios as if they were offsets.  Over four master seeds:
+#   * veach-mis: every region-channel's mean ratio is within 1.6 % of 1.000 (19 of 21 within 1 %): no offset, asserted against 1.0 below;
+#   * Cornell: the means are stable (spread over seeds 0.2 - 1.1 %) and NOT 1: this build is 1.7 - 3.6 % brighter than rene's published image on
+#     the floor and the walls and 6.7 % on the ceiling -- 17 one-statement alternatives, the decomposition by bounce and the frame-count model in
+#     profiles/r04_cornell_offsets.txt do not explain it, and the checkout cannot say which code / scene revision / light made the PNG.  Pinned
+#     as a regression pin around the seed means (+- 1 %: a one-per-cent change of any one surface's energy fails).  (instance, quad) -> r, g, b.
 T2_CORNELL_RATIOS = {
-    (0, 0): (1.0205, 1.0169, None), (1, 0): (1.0638, 1.0647, None), (2, 0): (1.0326, 1.0315, 1.0266),
-    (3, 0): (1.0284, 1.0276, None), (4, 0): (1.0373, None, None), (5, 1): (None, 1.0135, None),
-    (6, 1): (1.0194, 1.0157, None), (6, 4): (0.9888, None, None),
-}
-T2_VEACH_RATIOS = {
-    (0, 1): (0.9978, 0.9979, 0.9979), (0, 5): (1.0279, None, None), (1, 1): (0.9949, 0.9948, 0.9948), (1, 5): (1.0154, None, None),
-    (2, 1): (0.9934, 0.9925, 0.9925), (2, 5): (1.0201, None, None), (3, 0): (0.9849, 0.9825, 0.9817), (4, 0): (0.9819, 0.9811, 0.9809),
-    (8, 1): (0.9781, 0.9733, 0.9728),
+    (0, 0): (1.019, 1.017, None), (1, 0): (1.067, 1.069, None), (2, 0): (1.036, 1.035, 1.034),
+    (3, 0): (1.031, 1.029, None), (4, 0): (1.034, None, None), (5, 1): (None, 1.005, None),
+    (6, 1): (1.013, 1.013, None), (6, 4): (0.988, None, None),
 }
 T2_CORNELL_BOX4_RMSE = 0.0070  # measured 0.00565 (x 1.24); 8 x 8 boxes at 2048 spp: 0.0057
 T2_VEACH_BOX4_RMSE = 0.0114    # measured 0.00919 (x 1.24)
 
 
-def _check_regions(rows, expected):
-    checked = 0
-    for i, q, c, b, r in rows:
-        for ch in range(3):
-            if 0.03 <= b[ch] < 0.9:
-                want = expected.get((i, q), (None, None, None))[ch]
-                assert want is not None, f"region ({i}, {q}) channel {ch} (rene {b[ch]:.4f}, ratio {r[ch]:.4f}) has no recorded ratio"
-                assert abs(r[ch] - want) < 0.01, (i, q, ch, float(r[ch]), want)
-                checked += 1
-    return checked
+def _resolved(rows):
+    """(instance, quad, channel, ratios over seeds) for the region-channels rene's 8 bits resolve: mean linear in [0.03, 0.9) -- a quantisation
+    step is then below 3 % and the image's own noise dithers it"""
+    return [(i, q, ch, r[:, ch]) for i, q, c, b, r in rows for ch in range(3) if 0.03 <= b[ch] < 0.9]
 
 
 def test_t2_cornell_at_renes_5000_spp_box4_and_every_surface(oracle_mod):
     """rene's Cornell at rene's own sample count against rene's PNG: 4 x 4 box sRGB RMSE, and the mean linear radiance of every
-    surface the camera sees (walls, floor, ceiling, the visible faces of both blocks; tests/t2_regions.py)."""
+    surface the camera sees (walls, floor, ceiling, the visible faces of both blocks; tests/t2_regions.py), mean over four master seeds."""
     rmse, rows = _t2_regions("cornell", scenes.cornell_box(1024, 1024), oracle_mod)
     print("T2 Cornell 5000 spp, 4 x 4 box sRGB RMSE vs rene:", rmse)
     print(_show(rows))
     assert rmse < T2_CORNELL_BOX4_RMSE
-    assert _check_regions(rows, T2_CORNELL_RATIOS) >= 14
+    checked = 0
+    for i, q, ch, r in _resolved(rows):
+        want = T2_CORNELL_RATIOS.get((i, q), (None, None, None))[ch]
+        assert want is not None, f"region ({i}, {q}) channel {ch} (ratios {r}) has no recorded ratio"
+        assert abs(r.mean() - want) < 0.01, (i, q, ch, float(r.mean()), want)
+        assert r.max() - r.min() < 0.035, (i, q, ch, r)  # the seed scatter itself stays what the frame counts allow (measured: <= 0.025)
+        checked += 1
+    assert checked >= 14
 
 
 def test_t2_veach_mis_at_renes_5000_spp_box4_and_every_surface(oracle_mod):
-    """The same for veach-mis (Metal plates, sphere emitters): every plate, the floor, the wall."""
+    """The same for veach-mis (Metal plates, sphere emitters): every plate, the floor, the wall -- here the mean over the master seeds EQUALS
+    rene's published image: every region-channel within 2 % of 1.0 (measured: within 1.6 %, 19 of 21 within 1 %)."""
     rmse, rows = _t2_regions("veach_mis", scenes.veach_mis(1280, 720), oracle_mod)
     print("T2 veach-mis 5000 spp, 4 x 4 box sRGB RMSE vs rene:", rmse)
     print(_show(rows))
     assert rmse < T2_VEACH_BOX4_RMSE
-    assert _check_regions(rows, T2_VEACH_RATIOS) >= 20
+    res = _resolved(rows)
+    assert len(res) >= 20
+    for i, q, ch, r in res:
+        assert abs(r.mean() - 1.0) < 0.02, (i, q, ch, float(r.mean()), r)
+    assert sum(abs(r.mean() - 1.0) < 0.01 for i, q, ch, r in res) >= len(res) - 4
 
 
 # ---- tier T3: where things are in rene's published teapot render (tests/t3_geometry.py) --------------------------------------
