@@ -101,20 +101,31 @@ Rccl* rccl() {
     const char* over = std::getenv("RENE_RCCL_LIB");
     const char* defaults[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     std::vector<const char*> names;
-    if (over && *over) names.push_back(over);
-    else names.assign(defaults, defaults + 3);
+    static std::vector<std::string> over_names;  // RENE_RCCL_LIB may hold several candidates, ':'-separated, tried in order like the defaults
+    if (over && *over) {
+      std::string all(over);
+      for (size_t b = 0; b <= all.size();) {
+        size_t e = all.find(':', b);
+        if (e == std::string::npos) e = all.size();
+        if (e > b) over_names.push_back(all.substr(b, e - b));
+        b = e + 1;
+      }
+      for (const std::string& n : over_names) names.push_back(n.c_str());
+    } else names.assign(defaults, defaults + 3);
     for (const char* n : names) {
       x->handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
       if (x->handle) break;
     }
-    const char* why = nullptr;
+    std::string why;  // a COPY: dlerror()'s buffer belongs to the loader and the next failing dlopen() rewrites it
     for (const char* n : names) {
       if (x->handle) break;
       x->handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-      if (!x->handle && !why) why = dlerror();  // dlerror() clears the message it returns: read it once
+      if (!x->handle && why.empty()) {
+        if (const char* m = dlerror()) why = m;
+      }
     }
     if (!x->handle) {
-      x->error = std::string("RCCL is not available: ") + (why ? why : "librccl.so not found");
+      x->error = std::string("RCCL is not available: ") + (why.empty() ? "librccl.so not found" : why);
       return x;
     }
     bool ok = true;

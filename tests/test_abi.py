@@ -223,6 +223,12 @@ def test_missing_rccl_is_an_error_code_not_a_crash():
     p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
     assert p.returncode == 0, p.stderr[-500:]
     assert "CODE -4" in p.stdout and "RCCL is not available" in p.stdout and "librccl-absent" in p.stdout, p.stdout
+    # several candidates that all fail, as on the default path of a host without RCCL -- the message kept is the FIRST failure's,
+    # copied before the next dlopen() rewrites the loader's buffer (it used to be a pointer into that buffer)
+    env = dict(os.environ, RENE_RCCL_LIB="/nonexistent/librccl-first.so:/nonexistent/" + "x" * 300 + ".so:/nonexistent/librccl-third.so")
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr[-500:]
+    assert "CODE -4" in p.stdout and "librccl-first" in p.stdout and "librccl-third" not in p.stdout, p.stdout
 
 
 def test_image_maps_are_rgba_and_rgb_is_padded():
