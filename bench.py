@@ -174,24 +174,14 @@ def run_config(name: str, device: int = 0):
             rr.sync()
             dt = time.perf_counter() - t1
             return dt, rr.stats(), rr.download(0)
-    # The BVH configurations are timed twice: with every pixel's frames summed strictly one after the other (the reference's order of
-    # additions, and the library's default), and with RENE_FLAG_FRAME_GROUPS -- two chains per pixel, added at the sync: the same paths,
-    # the image equal up to the rounding of the regrouped sums (checked here).  A job in strict order cannot end before its most expensive
-    # pixel has been through all its frames; `value` is the job with two chains, `strict_order` the other.
-    strict = None
-    grouped = not (api.pack_info(pk).features & 64) and api.pack_info(pk).n_nodes_main > 512 and not os.environ.get("RENE_BENCH_NO_FRAME_GROUPS")
-    if grouped:
-        dt0, s0, im0 = job(0)
-        strict = {"value": s0.rays / dt0 / 1e6, "seconds": dt0}
-    dt, s2, im = job(abi.FLAG_FRAME_GROUPS if grouped else 0)
+    # One job, the library's default path.  (Round 3 timed the BVH configurations twice -- strict frame order and, opt-in, two chains of
+    # frames per pixel; since round 4 every context renders a pixel's frames as eight chains, frame f in chain f % 8, and the image is
+    # cut-independent: there is one mode.  DESIGN.md section 4f.)
+    dt, s2, im = job(0)
     assert bool(np.isfinite(im).all()) and float(im.mean()) > 0.0, f"{name}: image empty or non-finite"
-    if grouped:
-        assert s0.rays == s2.rays and s0.paths == s2.paths, f"{name}: the two chains did not render the strict job's paths"
-        strict["max_rel_image_difference"] = float(np.abs(im - im0).max() / max(1e-30, float(np.abs(im0).max())))
-        assert strict["max_rel_image_difference"] <= 1e-3, f"{name}: the image with two chains is not the strict one's"
     rl2 = rooflines(name, s2.rays / dt, cus, bpr, s2.sclk_mhz or None)
     return {"workload": lab, "width": pk.xres, "height": pk.yres, "spp": spp, "frames_per_launch": fpl,
-            "frame_groups": 2 if grouped else 1, "strict_order": strict,
+            "frame_chains": 8,
             "triangles": api.pack_info(pk).n_triangles, "rays": s2.rays, "rays_per_path": s2.rays / max(1, s2.paths),
             "value": s2.rays / dt / 1e6, "unit": "Mrays/s", "seconds": dt, "ms_per_frame": dt / spp * 1e3,
             "launch_ms": s2.kernel_ms / max(1, s2.launches), "launch_period_ms": dt * 1e3 / max(1, s2.launches),

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RENE_ABI_VERSION 4u
+#define RENE_ABI_VERSION 5u
 
 typedef enum rene_status {
   RENE_OK = 0,
@@ -206,17 +206,16 @@ enum {
                                  between launches to hide, and no launch ever waits for another: the occasional stall of the
                                  two-stream scheme -- DESIGN.md section 4g -- has nothing left to come from.) */
   ,
-  RENE_FLAG_FRAME_GROUPS = 1u << 9 /* opt-in, BVH scenes rendered by the traversal-restart kernels on an unsharded context with a framebuffer of
-                                      its own (ignored elsewhere): the frames of a rene_render call are rendered as TWO independent chains per
-                                      pixel -- the first and the second half of the call's frames, each summed in frame order into an image of
-                                      its own -- and the two images are added when the context is next drained (rene_sync, rene_download,
-                                      rene_get_stats, ...).  A pixel's frames are otherwise rendered strictly one after the other (the
-                                      reference's order of additions, rene/src/main.rs:1315-1397), and a job cannot end before its most expensive
-                                      pixel has been through all of them: rene's teapot scene at 8192 spp ends 13 % after its median wave.  Same
-                                      paths, same counters; the image equals the default one up to the rounding of the regrouped fp32 sums (as
-                                      RENE_SHARD_FRAMES does across GPUs) and is still identical from run to run, but no longer independent of
-                                      how a job is cut into rene_render calls.  n_frames of every call must be even; rene_framebuffer waits for the launches
-                                      (the image is one image only once the chains have been added). */
+  RENE_FLAG_FRAME_GROUPS = 1u << 9 /* accepted and ignored since ABI v5: what it asked for is how every context renders.  A pixel's frames are
+                                      EIGHT independent chains -- global frame f belongs to chain f % 8 (under RENE_SHARD_FRAMES: (f / shard_count) % 8),
+                                      each chain summed in frame order into an image of its own, across rene_render calls -- and the image a call hands
+                                      out (rene_download, rene_framebuffer, rene_reduce, rene_gather_tiles, the caller's opts.framebuffer after rene_sync)
+                                      is ((c0 + c1) + c2) + ... + c7.  The reference adds every frame onto the last (rene/src/main.rs:1315-1397), which
+                                      on a persistent kernel makes a pixel's frames one sequential chain: a job could not end before its most expensive
+                                      pixel had been through all its frames (rene's teapot scene at 8192 spp ended 13 % after its median wave) and a
+                                      tile shard had fewer chains than the chip has lanes.  The rule is on the frame NUMBER, so the image is bit-identical
+                                      however a job is cut into calls, launches, work items and tile shards, as before; it differs from the strict
+                                      frame order only in the rounding of the regrouped fp32 sums (max 4e-5 of the image's maximum at 1024 - 8192 spp). */
 };
 enum { RENE_SHARD_TILES = 0, RENE_SHARD_FRAMES = 1 };
 
@@ -229,9 +228,10 @@ typedef struct rene_opts {
   uint32_t shard_rank;   /* this context renders tiles (or frames) with index % shard_count == shard_rank */
   uint32_t shard_count;  /* 0 or 1 = unsharded */
   uint32_t reserved;
-  void* framebuffer;     /* optional caller-owned DEVICE buffer of 3*yres*xres*4 floats (zeroed), else NULL.  The fourth
-                            float of every pixel belongs to the device (the version of the work item that committed the
-                            sums); read r, g, b only, and zero the image through rene_reset */
+  void* framebuffer;     /* optional caller-owned DEVICE buffer of 3*yres*xres*4 floats, else NULL: where the image is handed out.  The
+                            library writes it whenever launches are waited for (rene_sync, rene_download, rene_get_stats,
+                            rene_framebuffer, rene_reduce, rene_gather_tiles): r, g, b = the sums of the frames rendered so far
+                            (the eight frame chains added, see RENE_FLAG_FRAME_GROUPS), the fourth float 0; zero it through rene_reset */
   void* stream;          /* optional hipStream_t to launch on, else NULL (library-owned stream) */
 } rene_opts;
 
@@ -310,13 +310,14 @@ int rene_reset(rene_ctx* ctx);
  * rene dispatches one frame at a time, main.rs:1355-1372).  Few, long items cost the least bookkeeping; short ones balance
  * scenes whose pixels differ widely in cost and end the launch on a short tail.  Renders three launches of `n_frames` frames
  * per candidate (one item per pixel and launch, then items of 256, 128, ... 16 frames), keeps the fastest, then resets the
- * context like rene_reset.  Untuned contexts use n_frames / 16 frames per item (at least 64) with the small-scene kernels and
- * n_frames / 32 (at least 16) with the BVH kernels.  The choice changes no bit of any image -- a pixel's frames are added in
- * the same order however they are cut. */
+ * context like rene_reset.  Untuned contexts cut a pixel's frames into sixteen items per launch (of at least 64 frames) with the
+ * small-scene kernels and 32 (of at least 16, the last ones halving) with the BVH kernels, over its eight frame chains.  The choice
+ * changes no bit of any image -- a chain's frames are added in the same order however they are cut. */
 int rene_tune(rene_ctx* ctx, uint32_t n_frames);
 
 /* Device address of the accumulation image [3][yres][xres][4] f32 (for callers that run their own exchange, e.g.
- * torch.distributed; rene_reduce / rene_gather_tiles below do it inside the library). */
+ * torch.distributed; rene_reduce / rene_gather_tiles below do it inside the library).  Waits for the launches issued so far: the
+ * image is the frame chains added together, which happens then. */
 int rene_framebuffer(rene_ctx* ctx, void** device_ptr, size_t* n_floats);
 
 int rene_get_stats(rene_ctx* ctx, rene_stats* out);

@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 COMM_ID_BYTES = 128  # RENE_COMM_ID_BYTES (an ncclUniqueId)
 DEFAULT_SEED = 0x52454E45
 TILE_SIZE = 32

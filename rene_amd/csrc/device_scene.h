@@ -267,6 +267,19 @@ constexpr uint32_t MAX_LEVELS = (1u << VERSION_LEVEL_BITS) - 1u;
 constexpr uint32_t MAX_EPOCH = (1u << (32u - VERSION_LEVEL_BITS)) - 1u;
 constexpr uint32_t MAX_LAUNCH_FRAMES = 65536u;  // frames of one launch (its seed tables: SEED_TAB_*); rene_render cuts longer requests
 
+// Frame chains (round 4).  The reference adds every frame of a pixel onto the last (rene/src/main.rs:1315-1397: one dispatch per frame), which on a
+// persistent kernel makes a pixel's frames ONE sequential chain: a job cannot end before its most expensive pixel has been through all its frames
+// (rene's teapot scene at 8192 spp: the last wave ended 13 % after the median one), and a tile shard of an image has fewer chains than the chip has
+// lanes.  Here a pixel's frames are CHAINS = 8 independent chains: frame f belongs to chain (f / frame_stride) mod 8, chain g sums its frames in
+// frame order into image g of `RenderParams::framebuffer` ([CHAINS][3][H][W][4]), across launches; the image handed out is
+// ((((((c0 + c1) + c2) + c3) + c4) + c5) + c6) + c7 (resolve_chains_kernel), computed when a call hands it out.  A fixed rule on the frame NUMBER: the image
+// does not depend on how a job is cut into calls, launches, work items or tile shards (bit-identical, tests), and differs from the strict frame
+// order only in the rounding of the regrouped fp32 sums (max 4e-5 of the image's maximum at 1024 - 8192 spp; T1 against the oracle is untouched).
+constexpr uint32_t CHAINS_LOG2 = 3;
+constexpr uint32_t CHAINS = 1u << CHAINS_LOG2;
+// (a lane carries its item's pixel and chain in one register: x | y << 14 | chain << 28)
+constexpr uint32_t MAX_RESOLUTION = 16384u;
+
 // The launch's frame seeds in LDS.  RenderParams::seed_tab = word offset of the tables in the workgroup's LDS | shift << 24.
 //   shift == 0 (launches of at most SEED_TAB_DIRECT_MAX frames): T[i] = the seed of launch frame i -- one ds_read per path start;
 //   shift >= 5: two levels -- the generator state of launch frame i is T1[i >> shift] pushed on by j = i & (2^shift - 1) frame
@@ -289,7 +302,7 @@ inline uint32_t seed_tab_words(uint32_t n_frames) {
 }
 
 struct RenderParams {
-  float* framebuffer;      // [3][H][W][4]: r, g, b sums + the record's version (device_code.inc, fb_store)
+  float* framebuffer;      // [CHAINS][3][H][W][4]: per chain r, g, b sums + the record's version (device_code.inc, fb_store)
   uint32_t seed_state0;    // state of PCG32si::new(master seed): the seed of global frame g is the stream's g-th output
   uint32_t first_frame;    // global number of the launch's frame 0 ...
   uint32_t frame_stride;   // ... and of the step to its next one (RENE_SHARD_FRAMES deals frames round-robin; else 1)
@@ -297,14 +310,14 @@ struct RenderParams {
   uint32_t* work_counter;  // next work id
   unsigned long long* counters;  // 9 x u64
   uint32_t n_frames;
-  uint32_t n_work;         // work ids: owned tiles * 1024
+  uint32_t n_work;         // work ids of one level: owned tiles * 1024 * CHAINS (id within the level = pixel slot * CHAINS + chain)
   uint32_t shard_rank, shard_count;  // tile sharding (shard_count == 1: all tiles)
   uint32_t tiles_x, n_tiles;
   uint32_t flags;
   uint32_t n_levels;       // every pixel's frames are cut into n_levels work items (ordered hand-off): n_uniform items of level_step
                            // frames, then the rest in halving items (device_code.inc, item_frames)
   uint32_t epoch;          // launch number (1 .. MAX_EPOCH); a pixel record's version is epoch << VERSION_LEVEL_BITS | items committed
-  uint32_t* item_done;     // [H][W] the same versions for the traversal-restart kernels, whose records are 12 bytes
+  uint32_t* item_done;     // [CHAINS][H][W] the same versions for the traversal-restart kernels, whose records are 12 bytes
   uint32_t ready_min;      // traversal-restart kernel: lanes waiting before the logic step runs
   uint32_t leaf_min;       // traversal-restart kernel: lanes at a leaf before the leaf step runs
   uint32_t level_step;     // frames per uniform work item: item (level < n_uniform, pixel) renders frames [level * step, (level + 1) * step)
@@ -316,10 +329,10 @@ struct RenderParams {
   uint32_t prev_final;     // version the context's previous launch left on every pixel record (0: a zeroed image):
                            // what a pixel's first item continues from (launches are serial: it is there)
   float inv_n_work, inv_tiles_x;  // 1.0f / n_work, 1.0f / tiles_x (udiv_small in the work-item bookkeeping)
-  uint32_t groups_log2;    // RENE_FLAG_FRAME_GROUPS (traversal-restart kernels): a pixel's frames are rendered as 2^groups_log2 independent chains,
-                           // chain g into an image of its own (the [3][H][W][4] block g of `framebuffer`, the [H][W] block g of `item_done`);
-                           // n_work then counts every chain's slots (2^groups_log2 x owned tiles x 1024); 0: one chain, as ever
-  uint32_t group_frames;   // frames of the launch per chain (n_frames >> groups_log2; n_frames when there is one): what item_frames cuts
+  uint32_t chain_phase;    // frame chains: the launch's frame i (global frame first_frame + i * frame_stride) belongs to chain (chain_phase + i) % CHAINS,
+                           // chain g into image g of `framebuffer` ([CHAINS][3][H][W][4]) and block g of `item_done` ([CHAINS][H][W])
+  uint32_t group_frames;   // the most frames of the launch any chain has, ceil(n_frames / CHAINS): what item_frames cuts (an item's range is clipped
+                           // to its own chain's count, which may be one less)
   unsigned long long* wave_times;  // RENE_DEBUG: [waves][2] start / end of every wave on the 100 MHz clock, else null
 };
 

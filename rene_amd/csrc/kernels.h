@@ -58,8 +58,8 @@ hipError_t launch_pcg_probe(uint32_t seed, uint32_t n, uint32_t* out, hipStream_
 // buffer [owned tile][layer][32][32][4] (out-of-image texels of edge tiles are zero / skipped)
 hipError_t launch_pack_tiles(const float* fb, float* packed, uint32_t width, uint32_t height, uint32_t tiles_x, uint32_t n_tiles,
                              uint32_t shard_rank, uint32_t shard_count, bool unpack, hipStream_t st);
-// RENE_FLAG_FRAME_GROUPS: fb = [groups][3][H][W][4]; image 0 += images 1 .. groups - 1, which are zeroed
-hipError_t launch_resolve_groups(float* fb, size_t image_floats, uint32_t groups, hipStream_t st);
+// frame chains: out[3][H][W][4] = the CHAINS images of `chains` added in chain order (alpha 0); the chains are left as they are
+hipError_t launch_resolve_chains(const float* chains, float* out, size_t image_floats, hipStream_t st);
 int render_block_size();
 
 }  // namespace rene

@@ -66,25 +66,28 @@ hipError_t launch_pcg_probe(uint32_t seed, uint32_t n, uint32_t* out, hipStream_
   return hipGetLastError();
 }
 
-// frame groups (RenderParams.groups_log2): the chains' images added onto the first, chain by chain, and zeroed -- what a call that hands
-// the image out (rene_sync, rene_download, rene_reduce, ...) sees is one image again; 16 bytes per thread
-__global__ void __launch_bounds__(BLOCK) resolve_groups_kernel(float4* fb, size_t n4, uint32_t groups) {
+// frame chains (device_scene.h, CHAINS): the image a call hands out = the chains' images added in chain order, ((c0 + c1) + c2) + ... -- the chains
+// themselves are left as they are (they go on accumulating across launches); the alpha channel of the output is 0 (lib.rs:170 never writes it;
+// in the chains' images it holds the records' versions); 16 bytes per thread
+__global__ void __launch_bounds__(BLOCK) resolve_chains_kernel(const float4* chains, float4* out, size_t n4) {
   const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n4) return;
-  float4 a = fb[i];
-  for (uint32_t g = 1; g < groups; ++g) {
-    const float4 b = fb[(size_t)g * n4 + i];
+  float4 a = chains[i];
+#pragma unroll
+  for (uint32_t g = 1; g < CHAINS; ++g) {
+    const float4 b = chains[(size_t)g * n4 + i];
     a.x += b.x;
     a.y += b.y;
     a.z += b.z;
-    fb[(size_t)g * n4 + i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  fb[i] = a;
+  a.w = 0.0f;
+  out[i] = a;
 }
-hipError_t launch_resolve_groups(float* fb, size_t image_floats, uint32_t groups, hipStream_t st) {
+hipError_t launch_resolve_chains(const float* chains, float* out, size_t image_floats, hipStream_t st) {
   const size_t n4 = image_floats / 4;
-  if (groups < 2 || n4 == 0) return hipSuccess;
-  hipLaunchKernelGGL(resolve_groups_kernel, dim3((unsigned)((n4 + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, reinterpret_cast<float4*>(fb), n4, groups);
+  if (n4 == 0) return hipSuccess;
+  hipLaunchKernelGGL(resolve_chains_kernel, dim3((unsigned)((n4 + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, st, reinterpret_cast<const float4*>(chains),
+                     reinterpret_cast<float4*>(out), n4);
   return hipGetLastError();
 }
 

@@ -103,7 +103,7 @@ int main(int argc, char** argv) {
   auto t_start = std::chrono::steady_clock::now();
   std::string pbrt_path, aov_normal, aov_albedo, denoiser = "none", dump_module, out_override;
   uint32_t spp = 5000, batch = 100, seed = RENE_DEFAULT_SEED, width = 0, height = 0, gpus = 1;
-  bool frame_groups = false;  // RENE_FLAG_FRAME_GROUPS: every batch's frames as two chains per pixel (additive; one GPU, BVH scenes)
+  bool frame_groups = false;  // --frame-groups (round 3's opt-in): accepted and ignored, every context renders eight frame chains per pixel (ABI v5)
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
     auto val = [&](const char* name) -> const char* {
@@ -151,10 +151,6 @@ int main(int argc, char** argv) {
     return 0;
   }
   if (pbrt_path.empty() || spp == 0 || batch == 0 || gpus == 0) { usage(); return 2; }
-  if (frame_groups) {  // two chains per pixel want an even number of frames per rene_render call
-    if (spp & 1u) { std::fprintf(stderr, "rene-hip: --frame-groups needs an even --spp\n"); return 2; }
-    batch = std::max(2u, batch & ~1u);
-  }
 
   rene_scene* scene = nullptr;
   if (rene_scene_load_pbrt(pbrt_path.c_str(), &scene) != RENE_OK) {
@@ -186,7 +182,7 @@ int main(int argc, char** argv) {
     o.shard_mode = RENE_SHARD_TILES;
     o.shard_rank = g;
     o.shard_count = gpus;
-    if (frame_groups && gpus == 1) o.flags |= RENE_FLAG_FRAME_GROUPS;
+    if (frame_groups) o.flags |= RENE_FLAG_FRAME_GROUPS;
     // all three layers are accumulated whether or not --aov-* asks for the files, like the reference's raygen
     // (lib.rs:229-232); RENE_FLAG_NO_AOV would save little and its Matte item-loop kernel happens to be the slower one
     if (rene_create(&desc, &o, &ctx[g]) != RENE_OK) return die("rene_create");

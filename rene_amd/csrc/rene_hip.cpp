@@ -198,8 +198,10 @@ struct rene_ctx {
   float* fb = nullptr;
   bool own_fb = false;
   size_t fb_floats = 0;
-  uint32_t groups_log2 = 0;     // RENE_FLAG_FRAME_GROUPS: every pixel's frames as 2^groups_log2 chains, each into an image of its own behind `fb`;
-                                // drain() adds the chains' images onto the first and zeroes them (resolve_groups)
+  // frame chains (device_scene.h, CHAINS): the kernels accumulate into `chains`, [CHAINS][3][H][W][4], the library's own; `fb` -- the context's or
+  // the caller's -- is the image handed out: the chains added in chain order whenever a drain finds launches since the last one (`fb_stale`)
+  float* chains = nullptr;
+  bool fb_stale = false;
   static constexpr uint32_t kCounters = 60;  // launches between two drains: each takes its own zeroed work counter
   uint32_t* d_work_counters = nullptr;        // [kCounters]
   unsigned long long* d_wave_times = nullptr; // RENE_DEBUG: [kCounters][8192][2]
@@ -211,7 +213,7 @@ struct rene_ctx {
   static constexpr uint32_t kWholeLaunch = 0xffffffffu;
   uint32_t item_frames = 0;
   std::vector<uint32_t> inst_material;  // material index of every instance (rene_bsdf_eval looks an instance of its material up)
-  uint32_t* d_item_done = nullptr;  // [H][W] versions, traversal-restart kernels only (device_code.inc, item_flag_publish)
+  uint32_t* d_item_done = nullptr;  // [CHAINS][H][W] versions, traversal-restart kernels only (device_code.inc, item_flag_publish)
   unsigned long long* d_counters = nullptr;
   // stage-separated wavefront integrator (BVH scenes): path state in HBM + a pinned word for the host loop
   bool wavefront = false;
@@ -342,7 +344,7 @@ struct rene_ctx {
           unsigned long long t[4] = {0, 0, 0, 0};
           hipMemcpy(t, d_counters + 8, sizeof(t), hipMemcpyDeviceToHost);
           std::fprintf(stderr, "[rene] %llu work items were dropped (the first: pixel (%llu, %llu), in launch %llu, wanted version %llu, saw %llu): launching the last %zu launch(es), %u..%u, again, serially (attempt %d)\n",
-                       dropped, t[1] & 0xffffull, t[1] >> 16, t[2] >> 32, t[3], t[2] & 0xffffffffull, pending.size(), pending.front().epoch, pending.back().epoch, attempt + 1);
+                       dropped, t[1] & 0x3fffull, (t[1] >> 14) & 0x3fffull, t[2] >> 32, t[3], t[2] & 0xffffffffull, pending.size(), pending.front().epoch, pending.back().epoch, attempt + 1);
         }
         HIP_TRY(zero_now(d_counters + 8, 4 * sizeof(unsigned long long)));
         for (Pending& p : pending) {
@@ -378,14 +380,15 @@ struct rene_ctx {
       HIP_TRY(hipMemcpy(t, d_counters + 8, sizeof(t), hipMemcpyDeviceToHost));
       handoff_failed = t[0] != 0;
       if (handoff_failed)
-        handoff_detail = " [" + std::to_string(t[0]) + " lanes gave up; the first: pixel (" + std::to_string(t[1] & 0xffffull) + ", " + std::to_string(t[1] >> 16) + "), in launch " +
+        handoff_detail = " [" + std::to_string(t[0]) + " lanes gave up; the first: pixel (" + std::to_string(t[1] & 0x3fffull) + ", " + std::to_string((t[1] >> 14) & 0x3fffull) + "), in launch " +
                          std::to_string(t[2] >> 32) + ", wanted version " + std::to_string(t[3]) + ", saw " + std::to_string(t[2] & 0xffffffffu) + "]";
     }
     if (handoff_failed) return fail(RENE_ERR_DEVICE, "work items were dropped inside the render kernel and replaying their launches did not complete them (results invalid; rene_reset clears the condition)" + handoff_detail);
-    if (groups_log2 && had_launches) {  // frame groups: the chains' images onto the first (the stream is idle; the next launch's chains start from zero sums)
-      hipError_t e = rene::launch_resolve_groups(fb, fb_floats, 1u << groups_log2, stream);
-      if (e != hipSuccess) return fail(RENE_ERR_DEVICE, std::string("resolve_groups: ") + hipGetErrorString(e));
+    if (fb_stale) {  // frame chains: the image handed out = the chains added in chain order (the chains go on accumulating)
+      hipError_t e = rene::launch_resolve_chains(chains, fb, fb_floats, stream);
+      if (e != hipSuccess) return fail(RENE_ERR_DEVICE, std::string("resolve_chains: ") + hipGetErrorString(e));
       HIP_TRY(wait_stream(stream));
+      fb_stale = false;
     }
     return RENE_OK;
   }
@@ -471,8 +474,8 @@ static int rene_create_impl(const rene_scene_desc* scene, const rene_opts* opts,
   if (n_dev <= 0) return fail(RENE_ERR_DEVICE, "no HIP device visible (the render path has no CPU fallback)");
   if (o.device < 0 || o.device >= n_dev) return fail(RENE_ERR_INVALID_ARGUMENT, "device ordinal out of range");
   HIP_TRY(hipSetDevice(o.device));
-  if (ps.width > 65535u || ps.height > 65535u)  // a lane keeps its pixel as x | y << 16
-    return fail(RENE_ERR_INVALID_ARGUMENT, "resolutions above 65535 are not supported");
+  if (ps.width > rene::MAX_RESOLUTION || ps.height > rene::MAX_RESOLUTION)  // a lane keeps its pixel and chain as x | y << 14 | chain << 28
+    return fail(RENE_ERR_INVALID_ARGUMENT, "resolutions above 16384 are not supported");
   for (int i = 0; i < 16; ++i)  // the kernels read the camera's origin off the matrix instead of multiplying a zero point through it
     if (!std::isfinite(ps.uniform.camera_to_world[i]) || !std::isfinite(ps.uniform.projection_inv[i]))
       return fail(RENE_ERR_INVALID_ARGUMENT, "rene_uniform: camera_to_world / projection_inv must be finite");
@@ -598,9 +601,9 @@ static int rene_create_impl(const rene_scene_desc* scene, const rene_opts* opts,
     tile_count = o.shard_count;
   }
   uint32_t owned = c->n_tiles > tile_rank ? (c->n_tiles - tile_rank + tile_count - 1) / tile_count : 0;
-  // work ids are 32-bit: id = level * n_work + slot with up to 31 levels, and udiv_small needs ids below 2^31
-  if ((uint64_t)owned * RENE_TILE_SIZE * RENE_TILE_SIZE * 32ull >= (1ull << 31))
-    return fail(RENE_ERR_UNSUPPORTED, "image too large: more than 2^26 pixels per GPU (shard it by tiles)");
+  // work ids are 32-bit: id = level * n_work + (pixel slot * CHAINS + chain) with room for 32 levels, and udiv_small needs ids below 2^31
+  if ((uint64_t)owned * RENE_TILE_SIZE * RENE_TILE_SIZE * rene::CHAINS * 32ull >= (1ull << 31))
+    return fail(RENE_ERR_UNSUPPORTED, "image too large: more than 2^23 pixels per GPU (shard it by tiles)");
   c->n_work = owned * RENE_TILE_SIZE * RENE_TILE_SIZE;
   // pixels of the image inside the owned tiles: paths per rendered frame (the kernels do not count what the host knows)
   c->owned_pixels = 0;
@@ -610,17 +613,11 @@ static int rene_create_impl(const rene_scene_desc* scene, const rene_opts* opts,
   }
 
   c->fb_floats = (size_t)3 * ps.width * ps.height * 4;
-  // Frame groups: only where the traversal-restart kernels render (render_wf.inc implements the chains), into a framebuffer of the
-  // context's own (a caller's is one image), on an unsharded context; everything else renders one chain as ever.
-  if ((o.flags & RENE_FLAG_FRAME_GROUPS) && !o.framebuffer && o.shard_count <= 1 && !(o.flags & (RENE_FLAG_NO_RESTART | RENE_FLAG_WAVEFRONT)) &&
-      !(c->cfg.features & rene::FEAT_SMALL) && ps.main.nodes.size() > 512) {  // (both integrators: kernels_bvh.hip and kernels_vol.hip pick the restart kernel by the same rule)
-    c->groups_log2 = 1;
-    if (const char* e = std::getenv("RENE_FRAME_GROUPS")) c->groups_log2 = std::atoi(e) >= 4 ? 2u : std::atoi(e) >= 2 ? 1u : 0u;  // tuning knob: 1, 2 or 4 chains
-  }
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->chains), (size_t)rene::CHAINS * c->fb_floats * sizeof(float)));  // frame chains (device_scene.h)
   if (o.framebuffer) {
     c->fb = static_cast<float*>(o.framebuffer);
   } else {
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->fb), (c->fb_floats << c->groups_log2) * sizeof(float)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->fb), c->fb_floats * sizeof(float)));
     c->own_fb = true;
   }
   // Which integrator renders this scene: the item-loop megakernel (small scenes), the volpath megakernel,
@@ -659,9 +656,10 @@ static int rene_create_impl(const rene_scene_desc* scene, const rene_opts* opts,
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_work_counters), rene_ctx::kCounters * sizeof(uint32_t)));
   HIP_TRY(hipMemsetAsync(c->d_work_counters, 0, rene_ctx::kCounters * sizeof(uint32_t), c->stream));
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_counters), 32 * sizeof(unsigned long long)));
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_item_done), ((size_t)ps.width * ps.height << c->groups_log2) * sizeof(uint32_t)));  // one version word per pixel (and chain)
-  HIP_TRY(hipMemsetAsync(c->d_item_done, 0, ((size_t)ps.width * ps.height << c->groups_log2) * sizeof(uint32_t), c->stream));
-  HIP_TRY(hipMemsetAsync(c->fb, 0, (c->fb_floats << (c->own_fb ? c->groups_log2 : 0u)) * sizeof(float), c->stream));  // main.rs:1229-1237
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_item_done), (size_t)rene::CHAINS * ps.width * ps.height * sizeof(uint32_t)));  // one version word per pixel and chain
+  HIP_TRY(hipMemsetAsync(c->d_item_done, 0, (size_t)rene::CHAINS * ps.width * ps.height * sizeof(uint32_t), c->stream));
+  HIP_TRY(hipMemsetAsync(c->chains, 0, (size_t)rene::CHAINS * c->fb_floats * sizeof(float), c->stream));  // main.rs:1229-1237
+  HIP_TRY(hipMemsetAsync(c->fb, 0, c->fb_floats * sizeof(float), c->stream));
   HIP_TRY(hipMemsetAsync(c->d_counters, 0, 32 * sizeof(unsigned long long), c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   HIP_TRY(hipDeviceSynchronize());  // everything the uploads left on the null stream (the fills of empty tables) has run: see zero_now
@@ -687,6 +685,7 @@ void rene_destroy(rene_ctx* c) {
   }
   for (void* p : c->allocations) hipFree(p);
   if (c->own_fb && c->fb) hipFree(c->fb);
+  if (c->chains) hipFree(c->chains);
   if (c->d_work_counters) hipFree(c->d_work_counters);
   if (c->d_wave_times) hipFree(c->d_wave_times);
   if (c->d_counters) hipFree(c->d_counters);
@@ -725,8 +724,6 @@ static int rene_render_impl(rene_ctx* c, uint32_t first_frame, uint32_t n_frames
     my_stride = n;
     my_count = skip < n_frames ? (n_frames - skip + n - 1) / n : 0;
   }
-  if (c->groups_log2 && (my_count & ((1u << c->groups_log2) - 1u)))
-    return fail(RENE_ERR_INVALID_ARGUMENT, "RENE_FLAG_FRAME_GROUPS: the frames of a rene_render call must be a multiple of the number of chains (2)");
   c->frames += n_frames;
   if (my_count == 0 || c->n_work == 0) return RENE_OK;
   c->paths += (uint64_t)my_count * c->owned_pixels;
@@ -758,7 +755,7 @@ static int rene_render_impl(rene_ctx* c, uint32_t first_frame, uint32_t n_frames
   if (e == hipSuccess) e = hipEventCreate(&pend.stop);
   if (e != hipSuccess) return fail(RENE_ERR_DEVICE, std::string("rene_render setup: ") + hipGetErrorString(e));
   rene::RenderParams P{};
-  P.framebuffer = c->fb;
+  P.framebuffer = c->chains;
   P.seed_state0 = HostPcg(c->opts.seed).s;
   P.first_frame = my_first;
   P.frame_stride = my_stride;
@@ -767,9 +764,11 @@ static int rene_render_impl(rene_ctx* c, uint32_t first_frame, uint32_t n_frames
   P.item_done = c->d_item_done;
   P.counters = c->d_counters;
   P.n_frames = my_count;
-  P.n_work = c->n_work << c->groups_log2;  // (a level's work ids: the slots of chain 0, then those of chain 1, ...)
-  P.groups_log2 = c->groups_log2;
-  P.group_frames = my_count >> c->groups_log2;
+  // frame chains (device_scene.h): global frame f belongs to chain (f / frame_stride) % CHAINS -- a rule on the frame's number, so that a pixel's
+  // chains hold the same sums however a job is cut into calls; a level's work ids: pixel slot * CHAINS + chain
+  P.n_work = c->n_work * rene::CHAINS;
+  P.chain_phase = (my_first / my_stride) & (rene::CHAINS - 1u);
+  P.group_frames = (my_count + rene::CHAINS - 1u) / rene::CHAINS;
   P.shard_rank = c->opts.shard_mode == RENE_SHARD_TILES ? c->opts.shard_rank : 0;
   P.shard_count = c->opts.shard_mode == RENE_SHARD_TILES ? c->opts.shard_count : 1;
   P.tiles_x = c->tiles_x;
@@ -799,11 +798,13 @@ static int rene_render_impl(rene_ctx* c, uint32_t first_frame, uint32_t n_frames
     // item: 6.89 / 6.59 / 6.59 / 6.41 ms; 256 frames, 16 / 32 / 64 / 128: 13.30 / 13.13 / 13.21 / 12.84; 512 frames, 32 / 64 / 128: 24.93 / 24.74 / 25.23)
     // (frame groups: a chain has half the frames and wants items as long as the undivided job's, or longer -- dragon-class, two chains of 512
     // frames: items of 16 / 32 / 64 frames 671 / 653 / 642 ms; the teapot scene, two chains of 4096: 128 / 256 / 512 / 1024 frames 3139 / 3106 / 3179 / 3157 ms)
-    uint32_t item = c->item_frames ? c->item_frames : ((c->cfg.features & rene::FEAT_SMALL) ? std::max(64u, F / 16u) : std::max(16u, c->groups_log2 ? F / 16u : F / 32u));
+    // (frame chains, round 4: F is what ONE of a pixel's CHAINS chains renders in this launch; the same item LENGTHS as before -- sixteen / 32 items
+    // per pixel and launch over all its chains)
+    uint32_t item = c->item_frames ? c->item_frames : ((c->cfg.features & rene::FEAT_SMALL) ? std::max(64u, F / (16u / rene::CHAINS)) : std::max(16u, F / (32u / rene::CHAINS)));
     uint32_t tail = item;
-    // (... and a halving tail: with half the frames per chain the end of the job is the last items again, not the heaviest pixel's chain --
+    // (... and for the BVH kernels a halving tail: with chains the end of the job is the end of its last items, not the heaviest pixel's chain --
     // dragon-class, two chains: items of 64 frames 651 ms, halving down to 8 frames 641; the teapot scene 256 -> 16 frames: 3140 -> 3092 ms)
-    if (c->groups_log2 && !c->item_frames) tail = std::max(4u, item / 8u);
+    if (!(c->cfg.features & rene::FEAT_SMALL) && !c->item_frames) tail = std::max(4u, item / 8u);
     if (const char* e = std::getenv("RENE_ITEM_FRAMES")) item = (uint32_t)std::max(1, std::atoi(e));  // tuning knobs
     if (const char* e = std::getenv("RENE_ITEM_TAIL")) tail = (uint32_t)std::max(1, std::atoi(e));
     if (const char* e = std::getenv("RENE_LEVELS")) {
@@ -839,8 +840,8 @@ static int rene_render_impl(rene_ctx* c, uint32_t first_frame, uint32_t n_frames
   }
   P.prev_final = c->prev_final;
   if (c->epoch >= rene::MAX_EPOCH) {  // (drained above) the epoch wraps: every pixel record back to version 0
-    hipMemset2DAsync(c->fb + 3, 4 * sizeof(float), 0, sizeof(float), c->fb_floats / 4, stream);
-    hipMemsetAsync(c->d_item_done, 0, ((size_t)c->width * c->height << c->groups_log2) * sizeof(uint32_t), stream);
+    hipMemset2DAsync(c->chains + 3, 4 * sizeof(float), 0, sizeof(float), (size_t)rene::CHAINS * c->fb_floats / 4, stream);
+    hipMemsetAsync(c->d_item_done, 0, (size_t)rene::CHAINS * c->width * c->height * sizeof(uint32_t), stream);
     c->epoch = 0;
     P.prev_final = 0;
   }
@@ -881,6 +882,7 @@ static int rene_render_impl(rene_ctx* c, uint32_t first_frame, uint32_t n_frames
     hipEventRecord(pend.stop, c->stream);
     c->pending.push_back(pend);
     c->launches++;
+    c->fb_stale = true;
     if (e != hipSuccess) return fail(RENE_ERR_DEVICE, std::string("wavefront launch: ") + hipGetErrorString(e));
     return c->drain();
   }
@@ -919,6 +921,7 @@ static int rene_render_impl(rene_ctx* c, uint32_t first_frame, uint32_t n_frames
   c->counters_used++;
   c->pending.push_back(pend);
   c->launches++;
+  c->fb_stale = true;
   if (c->pending.size() >= rene_ctx::kCounters) return c->drain();
   return RENE_OK;
 }
@@ -936,9 +939,11 @@ int rene_reset(rene_ctx* c) {
   if (rc != RENE_OK && !c->handoff_failed) return rc;
   c->handoff_failed = false;  // the counters are cleared below and the image starts again from zero
   c->exchanged = false;
-  HIP_TRY(hipMemsetAsync(c->fb, 0, (c->fb_floats << (c->own_fb ? c->groups_log2 : 0u)) * sizeof(float), c->stream));
+  HIP_TRY(hipMemsetAsync(c->chains, 0, (size_t)rene::CHAINS * c->fb_floats * sizeof(float), c->stream));
+  HIP_TRY(hipMemsetAsync(c->fb, 0, c->fb_floats * sizeof(float), c->stream));
+  c->fb_stale = false;
   HIP_TRY(hipMemsetAsync(c->d_counters, 0, 32 * sizeof(unsigned long long), c->stream));
-  HIP_TRY(hipMemsetAsync(c->d_item_done, 0, ((size_t)c->width * c->height << c->groups_log2) * sizeof(uint32_t), c->stream));
+  HIP_TRY(hipMemsetAsync(c->d_item_done, 0, (size_t)rene::CHAINS * c->width * c->height * sizeof(uint32_t), c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->prev_final = 0;  // the pixel records carry version 0 again
   c->frames = 0;
@@ -959,10 +964,11 @@ int rene_tune(rene_ctx* c, uint32_t n_frames) {
   const uint32_t saved = c->item_frames;
   uint32_t best = saved;
   double best_ms = 0.0;
-  // candidates: one item per pixel and launch, then items of 256 / 128 / 64 / 32 / 16 frames
+  // candidates: one item per pixel, chain and launch, then items of 256 / 128 / 64 / 32 / 16 frames (of the chain's share of the launch)
   const uint32_t items[6] = {rene_ctx::kWholeLaunch, 256u, 128u, 64u, 32u, 16u};
+  const uint32_t chain_frames = (n_frames + rene::CHAINS - 1u) / rene::CHAINS;
   for (int i = 0; i < 6; ++i) {
-    if (i > 0 && items[i] * 2u > n_frames) continue;
+    if (i > 0 && items[i] * 2u > chain_frames) continue;
     c->item_frames = items[i];
     const auto t0 = std::chrono::steady_clock::now();
     for (int k = 0; k < 3 && rc == RENE_OK; ++k) rc = rene_render(c, 0, n_frames);  // what is rendered does not matter
@@ -988,7 +994,7 @@ int rene_framebuffer(rene_ctx* c, void** device_ptr, size_t* n_floats) {
   *device_ptr = c->fb;
   if (n_floats) *n_floats = c->fb_floats;
   HIP_TRY(hipSetDevice(c->device));
-  if (c->groups_log2) {  // frame groups: the image is one image only after the chains have been added (drain), not in stream order
+  {  // frame chains: the image is the chains added together, which a drain does (not in stream order)
     int rc = c->drain();
     if (rc != RENE_OK) return rc;
   }

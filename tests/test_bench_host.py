@@ -62,16 +62,18 @@ def test_a_failing_or_stalling_configuration_becomes_an_error_entry(monkeypatch,
     json.dumps(out)
 
 
-def test_the_committed_bench_line_times_the_bvh_jobs_both_ways():
-    """bench.py's `configs`: the BVH configurations in the reference's strict frame order AND as two chains of frames per pixel
-    (RENE_FLAG_FRAME_GROUPS; `value` is the latter, `strict_order` the former, with how far the two images are apart); the
-    small scenes have no such tail and run one chain."""
+def test_the_committed_bench_line_carries_every_configuration():
+    """bench.py's `configs` (the latest committed line under profiles/): every BASELINE configuration beside the headline one, each rendered by
+    the library's default path -- since round 4 eight frame chains per pixel on every kernel (`frame_chains`); round 3's lines timed the BVH
+    configurations twice (strict frame order and two opt-in chains)."""
     import glob
     path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_bench.json")))[-1]
     d = json.loads(open(path).read().strip().splitlines()[-1])
     assert d["roofline"]["pmc_stale"] is False, path
-    for name in ("dragon-class", "teapot-class", "dragon-partial"):
+    for name in ("veach-mis", "dragon-class", "teapot-class", "dragon-partial", "material-zoo"):
         c = d["configs"][name]
-        assert c["frame_groups"] == 2 and c["strict_order"]["value"] > 0 and c["strict_order"]["max_rel_image_difference"] <= 1e-3, name
-    for name in ("veach-mis", "material-zoo"):
-        assert d["configs"][name]["frame_groups"] == 1 and d["configs"][name]["strict_order"] is None
+        assert c["value"] > 0 and c["rays"] > 0, name
+        if "frame_chains" in c:
+            assert c["frame_chains"] == 8 and "strict_order" not in c, name
+        else:  # a round-3 line
+            assert c["frame_groups"] in (1, 2), name

@@ -413,37 +413,42 @@ def test_soak_many_launches_none_replayed():
     assert np.isfinite(first).all() and first.sum() > 0
 
 
-@pytest.mark.parametrize("name", ["dragon", "teapot", "fog"])
-def test_frame_groups_render_the_same_paths_into_two_chains(name):
-    """RENE_FLAG_FRAME_GROUPS (include/rene_hip.h): the frames of a call as two independent chains per pixel, added when the context
-    is drained.  The paths are the default's (identical counters), the image the default's up to the rounding of the regrouped sums,
-    identical from run to run, over several calls and on top of an earlier sync; calls with an odd number of frames are refused,
-    and where the flag does not apply (small scenes) it changes nothing."""
+@pytest.mark.parametrize("name", ["dragon", "teapot", "fog", "cornell", "veach"])
+def test_frame_chains_do_not_depend_on_the_cut_and_sum_to_the_frames(name):
+    """Frame chains (device_scene.h, CHAINS; include/rene_hip.h, RENE_FLAG_FRAME_GROUPS): a pixel's frames are eight chains -- frame f in chain
+    f % 8, each summed in frame order into an image of its own across calls -- and the image handed out is the chains added in chain order.
+    The rule is on the frame's NUMBER: every cut of a job into calls gives the same bits (calls of odd lengths, single frames, a sync or a
+    download in between), on every kernel family; and the image is the sum of its frames: equal to the float64 sum of the frames rendered
+    one at a time up to fp32 rounding."""
     s = {"dragon": lambda: scenes.dragon_class(160, 90, 40, 44), "teapot": lambda: scenes.teapot_class(128, 72, 40, 44),
-         "fog": lambda: scenes.dragon_fog(128, 72, 40, 44)}[name]()  # (fog: Integrator "volpath", the restart kernel of kernels_vol.hip)
-    assert api.pack_info(s).n_nodes_main > 512  # (shallower trees are rendered by the while-while kernel, where the flag does not apply)
+         "fog": lambda: scenes.dragon_fog(128, 72, 40, 44),  # (fog: Integrator "volpath", the restart kernel of kernels_vol.hip)
+         "cornell": lambda: scenes.cornell_box(96, 64), "veach": lambda: scenes.veach_mis(96, 54)}[name]()
     keys = ("rays_closest", "rays_shadow", "rays_emitter", "paths", "hits", "adds")
+    F = 35
     with api.Renderer(s) as r:
-        r.render(0, 24)
-        r.render(24, 8)
+        r.render(0, F)
         ref = [r.download(k) for k in range(3)]
         sr = r.stats().as_dict()
-    runs = []
-    for _ in range(2):
-        with api.Renderer(s, flags=abi.FLAG_FRAME_GROUPS) as g:
-            g.render(0, 24)
-            g.sync()  # (the chains are added here, and the next call's start again from zero)
-            g.render(24, 8)
-            runs.append([g.download(k) for k in range(3)])
+        per_frame = np.zeros(ref[0].shape, np.float64)
+        for f in range(F):
+            r.reset()
+            r.render(f, 1)
+            per_frame += r.download(0)
+    np.testing.assert_allclose(ref[0], per_frame, rtol=3e-6, atol=1e-6 * F)
+    for cut in ([24, 11], [5, 3, 17, 7, 3], [1] * F, [8, 8, 8, 8, 3], [9, 26]):
+        with api.Renderer(s) as g:
+            f0 = 0
+            for i, n in enumerate(cut):
+                g.render(f0, n)
+                f0 += n
+                if i == 0:
+                    g.sync()
+                if i == 1:
+                    g.download(1)  # (handing the image out adds the chains into the output and leaves them as they are)
+            for k in range(3):
+                np.testing.assert_array_equal(g.download(k), ref[k], err_msg=f"cut {cut} layer {k}")
             sg = g.stats().as_dict()
-            with pytest.raises(api.ReneError):
-                g.render(32, 3)
-    assert {k: sg[k] for k in keys} == {k: sr[k] for k in keys}
-    for k in range(3):
-        np.testing.assert_array_equal(runs[0][k], runs[1][k])
-        np.testing.assert_allclose(runs[0][k], ref[k], rtol=2e-6, atol=1e-6 * 32)
-    small = scenes.cornell_box(32, 32)
-    with api.Renderer(small) as a, api.Renderer(small, flags=abi.FLAG_FRAME_GROUPS) as b:
-        a.render(0, 5)
-        b.render(0, 5)
-        np.testing.assert_array_equal(a.download(0), b.download(0))
+        assert {k: sg[k] for k in keys} == {k: sr[k] for k in keys}, cut
+    with api.Renderer(s, flags=abi.FLAG_FRAME_GROUPS) as b:  # accepted and ignored
+        b.render(0, F)
+        np.testing.assert_array_equal(b.download(0), ref[0])
