@@ -288,6 +288,36 @@ def configs_in_children(head: str, timeout_s: float):
     return out
 
 
+class Watchdog:
+    """N > 1 only: `arm(phase, seconds)` starts a timer; if `disarm()` does not come in time, rank 0 prints ONE JSON error record (same keys as the
+    bench line, value null, `error` says which phase hung) and the process leaves with exit code 3 through os._exit -- from the timer's thread, because
+    the main thread is then inside a rendezvous or a collective that will not return.  One GPU: does nothing."""
+
+    def __init__(self, rank: int, world: int, n_gpus: int):
+        self.rank, self.world, self.n_gpus, self.timer = rank, world, n_gpus, None
+
+    def _fire(self, phase: str, seconds: float):
+        msg = f"rank {self.rank} of {self.world}: {phase} did not finish within {seconds:.0f} s"
+        print(f"[bench] {msg}; giving up", file=sys.stderr, flush=True)
+        if self.rank == 0:
+            print(json.dumps({"metric": "Mrays/s", "value": None, "unit": "Mrays/s", "n_gpus": self.n_gpus, "higher_is_better": True,
+                              "error": msg, "config": {"workload": "cornell-box 1024x1024 @ 1024 spp"}}), flush=True)
+        os._exit(3)
+
+    def arm(self, phase: str, seconds: float):
+        self.disarm()
+        if self.world > 1 or os.environ.get("RENE_BENCH_TEST_WATCHDOG"):
+            import threading
+            self.timer = threading.Timer(seconds, self._fire, (phase, seconds))
+            self.timer.daemon = True
+            self.timer.start()
+
+    def disarm(self):
+        if self.timer is not None:
+            self.timer.cancel()
+            self.timer = None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -299,6 +329,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--config-child", default=None, help=argparse.SUPPRESS)  # one additional configuration in this process (see configs_in_children)
     ap.add_argument("--config-timeout", type=float, default=300.0, help="seconds an additional configuration may take before it is given up")
+    ap.add_argument("--phase-timeout", type=float, default=150.0, help="N > 1: seconds the rendezvous, the communicator set-up and the warm-up may each take (the timed region: six times that) before the run gives up with an error record")
     args = ap.parse_args()
     if args.config_child:
         import torch
@@ -325,9 +356,16 @@ def main():
     backend = os.environ.get("RENE_DIST_BACKEND", "nccl")
     local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
+    # N > 1: nothing that can wait for another rank may wait for ever -- the driver has ONE scaling run.  A watchdog thread per rank, armed around
+    # the rendezvous, the communicator set-up, the warm-up (first exchange: RCCL builds its rings there) and the timed region: when a phase
+    # overruns, rank 0 prints an error record in the bench line's place and every rank leaves with a non-zero exit code (os._exit from the
+    # watchdog thread: the main thread may be inside a collective; the launcher then ends the other ranks).  Nothing is re-executed.
+    watchdog = Watchdog(rank, world, max(1, args.gpus))
     if world > 1:
+        watchdog.arm("rendezvous (torch.distributed.init_process_group)", args.phase_timeout)
         rdist.init_process_group(backend)
         import torch.distributed as dist
+        watchdog.disarm()
 
     cfgs = configurations()
     head = args.only or "cornell"
@@ -340,10 +378,13 @@ def main():
     WIDTH, HEIGHT = packed.xres, packed.yres
     n_triangles = api.pack_info(packed).n_triangles
 
-    by_tiles = os.environ.get("RENE_BENCH_SHARD", "frames") == "tiles"
-    # N > 1, default: STRONG scaling -- the job is the N = 1 line's (same image, same 1024 spp), its frames dealt to the
-    # ranks in contiguous blocks, then one reduce.  RENE_BENCH_SCALING=weak: every GPU renders 1024 frames of an N x 1024 spp
-    # image.  The tile cut shrinks a rank's share by construction, so it is always strong.
+    # N > 1, default since round 4: north_star's cut -- 32 x 32 pixel TILES round-robin over the GPUs, every rank all 1024 frames of its tiles,
+    # one gather of the owned tiles onto rank 0 (1 / N of the image per rank); the image is bit-identical to the one-GPU render.  (With a
+    # pixel's frames as eight chains a rank's eighth of the image fills the chip: render efficiency at N = 8 on one GPU's share 0.87, was 0.33;
+    # DESIGN.md section 6.)  RENE_BENCH_SHARD=frames: contiguous frame blocks + one reduce of the partial images instead.
+    by_tiles = os.environ.get("RENE_BENCH_SHARD", "tiles") == "tiles"
+    # STRONG scaling: the job is the N = 1 line's (same image, same 1024 spp).  RENE_BENCH_SCALING=weak (frame blocks only): every GPU renders
+    # 1024 frames of an N x 1024 spp image.  The tile cut shrinks a rank's share by construction, so it is always strong.
     weak = world > 1 and not by_tiles and os.environ.get("RENE_BENCH_SCALING", "strong") == "weak"
     JOB_SPP = SPP * world if weak else SPP
     t_rank, t_world = (rank, world) if by_tiles else (0, 1)
@@ -373,9 +414,11 @@ def main():
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         in_library = bool(ok.item() > 0)
         if in_library:
+            watchdog.arm("communicator set-up (rene_comm_init: ncclCommInitRank on every rank)", args.phase_timeout)
             uid = [my_uid if rank == 0 else None]
             dist.broadcast_object_list(uid, src=0)
             r.comm_init(world, rank, uid[0])
+            watchdog.disarm()
 
     def exchange():
         if world > 1:
@@ -401,9 +444,14 @@ def main():
     bytes_per_ray = algorithmic_bytes_per_ray(packed, api, abi, local, frames=min(F, 8) if head == "cornell" else 2, **shard)
 
     # ---- warmup (kernel + the collective: RCCL sets its rings up lazily) ----
-    for _ in range(Wm):
+    if world > 1:
+        watchdog.arm("warm-up jobs (the first exchange: RCCL builds its rings)", args.phase_timeout)
+    for _ in range(max(Wm, 1 if world > 1 else 0)):  # (N > 1: at least one untimed job, so that the timed region never holds the first exchange)
         job()
     torch.cuda.synchronize()
+    watchdog.disarm()
+    if world > 1:
+        watchdog.arm("timed region + the 8-GPU configurations", 6.0 * args.phase_timeout)
 
     def fence():
         torch.cuda.synchronize()
@@ -449,6 +497,7 @@ def main():
         for name in ("dragon-class", "teapot-class"):
             multi_configs[name] = run_config_sharded(name, local, rank, world, backend, in_library, by_tiles)
 
+    watchdog.disarm()
     if rank == 0:
         img = fb[0, :, :, :3]
         assert bool(torch.isfinite(img).all()) and float(img.mean()) > 0.0, "framebuffer is empty or non-finite"
@@ -502,6 +551,9 @@ def main():
         # ---- the other configurations, one full job each (N = 1 only; measured in child processes before this one started) ----
         if child_configs is not None:
             out["configs"] = child_configs
+            # (compact copy inside `config`, which the driver's record of the line keeps: name -> [Mrays/s, VALU issue frac, useful lane frac])
+            out["config"]["other_configs"] = {k: ([round(v["value"], 1), (v.get("valu") or {}).get("frac"), (v.get("valu") or {}).get("useful_lane_frac")]
+                                                  if isinstance(v, dict) and v.get("value") else [None, None, None]) for k, v in child_configs.items()}
         if multi_configs is not None:
             out["configs"] = multi_configs
         if n_gpus == 1 and not args.no_cpu_baseline:

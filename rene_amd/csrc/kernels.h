@@ -60,6 +60,9 @@ hipError_t launch_pack_tiles(const float* fb, float* packed, uint32_t width, uin
                              uint32_t shard_rank, uint32_t shard_count, bool unpack, hipStream_t st);
 // frame chains: out[3][H][W][4] = the CHAINS images of `chains` added in chain order (alpha 0); the chains are left as they are
 hipError_t launch_resolve_chains(const float* chains, float* out, size_t image_floats, hipStream_t st);
+// the same over the tiles a tile shard owns (tile t with t % shard_count == shard_rank); zero = true: clears the chains there instead
+hipError_t launch_chains_tiles(float* chains, float* out, bool zero, uint32_t width, uint32_t height, uint32_t tiles_x, uint32_t n_tiles,
+                               uint32_t shard_rank, uint32_t shard_count, hipStream_t st);
 int render_block_size();
 
 }  // namespace rene

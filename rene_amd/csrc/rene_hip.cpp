@@ -236,7 +236,7 @@ struct rene_ctx {
   // multi-GPU exchange (rene_comm_*): the RCCL communicator this context belongs to
   ncclComm_t comm = nullptr;
   int comm_ranks = 0, comm_rank = -1;
-  bool exchanged = false;  // an exchange has rewritten the records' version words: rene_reset before rendering again
+  bool exchanged = false;  // an exchange has put other ranks' sums into `fb`, which the next drain would overwrite with this context's chains: rene_reset before rendering again
   float* tile_buf = nullptr;  // rene_gather_tiles: packed owned tiles (root: of every rank)
   float* h_stage = nullptr;   // pinned host staging of one layer (rene_download)
   void* h_upload = nullptr;   // pinned host staging of the scene upload (rene_create), released when it is done
@@ -385,7 +385,9 @@ struct rene_ctx {
     }
     if (handoff_failed) return fail(RENE_ERR_DEVICE, "work items were dropped inside the render kernel and replaying their launches did not complete them (results invalid; rene_reset clears the condition)" + handoff_detail);
     if (fb_stale) {  // frame chains: the image handed out = the chains added in chain order (the chains go on accumulating)
-      hipError_t e = rene::launch_resolve_chains(chains, fb, fb_floats, stream);
+      const bool tiles = opts.shard_mode == RENE_SHARD_TILES && opts.shard_count > 1;  // (a tile shard: only the tiles it owns hold anything)
+      hipError_t e = tiles ? rene::launch_chains_tiles(chains, fb, false, width, height, tiles_x, n_tiles, opts.shard_rank, opts.shard_count, stream)
+                           : rene::launch_resolve_chains(chains, fb, fb_floats, stream);
       if (e != hipSuccess) return fail(RENE_ERR_DEVICE, std::string("resolve_chains: ") + hipGetErrorString(e));
       HIP_TRY(wait_stream(stream));
       fb_stale = false;
@@ -800,7 +802,11 @@ static int rene_render_impl(rene_ctx* c, uint32_t first_frame, uint32_t n_frames
     // frames: items of 16 / 32 / 64 frames 671 / 653 / 642 ms; the teapot scene, two chains of 4096: 128 / 256 / 512 / 1024 frames 3139 / 3106 / 3179 / 3157 ms)
     // (frame chains, round 4: F is what ONE of a pixel's CHAINS chains renders in this launch; the same item LENGTHS as before -- sixteen / 32 items
     // per pixel and launch over all its chains)
-    uint32_t item = c->item_frames ? c->item_frames : ((c->cfg.features & rene::FEAT_SMALL) ? std::max(64u, F / (16u / rene::CHAINS)) : std::max(16u, F / (32u / rene::CHAINS)));
+    // (BVH kernels, re-swept with chains on dragon-class, a chain's share F = 128 frames: the whole 2 M-pixel image wants items of 64 frames -- 648 ms
+    // against 654 at 32 and 667 at 16 -- and an eighth of its tiles items of 16 -- 93.3 ms against 98.8 at 32 and 108 at 64: what matters is how
+    // many items the context's lanes share, so the item shrinks with the pixels the context owns, F / 2 at 2 M pixels down to F / 8)
+    const uint32_t bvh_div = c->owned_pixels >= (3u << 19) ? 2u : c->owned_pixels >= (3u << 18) ? 4u : 8u;
+    uint32_t item = c->item_frames ? c->item_frames : ((c->cfg.features & rene::FEAT_SMALL) ? std::max(64u, F / (16u / rene::CHAINS)) : std::max(16u, F / bvh_div));
     uint32_t tail = item;
     // (... and for the BVH kernels a halving tail: with chains the end of the job is the end of its last items, not the heaviest pixel's chain --
     // dragon-class, two chains: items of 64 frames 651 ms, halving down to 8 frames 641; the teapot scene 256 -> 16 frames: 3140 -> 3092 ms)
@@ -939,7 +945,12 @@ int rene_reset(rene_ctx* c) {
   if (rc != RENE_OK && !c->handoff_failed) return rc;
   c->handoff_failed = false;  // the counters are cleared below and the image starts again from zero
   c->exchanged = false;
-  HIP_TRY(hipMemsetAsync(c->chains, 0, (size_t)rene::CHAINS * c->fb_floats * sizeof(float), c->stream));
+  if (c->opts.shard_mode == RENE_SHARD_TILES && c->opts.shard_count > 1) {  // a tile shard's chains hold something in the tiles it owns only
+    hipError_t e = rene::launch_chains_tiles(c->chains, c->fb, true, c->width, c->height, c->tiles_x, c->n_tiles, c->opts.shard_rank, c->opts.shard_count, c->stream);
+    if (e != hipSuccess) return fail(RENE_ERR_DEVICE, std::string("rene_reset: ") + hipGetErrorString(e));
+  } else {
+    HIP_TRY(hipMemsetAsync(c->chains, 0, (size_t)rene::CHAINS * c->fb_floats * sizeof(float), c->stream));
+  }
   HIP_TRY(hipMemsetAsync(c->fb, 0, c->fb_floats * sizeof(float), c->stream));
   c->fb_stale = false;
   HIP_TRY(hipMemsetAsync(c->d_counters, 0, 32 * sizeof(unsigned long long), c->stream));

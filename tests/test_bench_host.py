@@ -77,3 +77,25 @@ def test_the_committed_bench_line_carries_every_configuration():
             assert c["frame_chains"] == 8 and "strict_order" not in c, name
         else:  # a round-3 line
             assert c["frame_groups"] in (1, 2), name
+
+
+def test_the_watchdog_turns_a_hung_phase_into_an_error_record_and_a_non_zero_exit():
+    """`bench.py --gpus N` must not hang the driver's one scaling run.  A phase that overruns (here: a sleep standing in for
+    a rendezvous that never completes) makes rank 0 print ONE JSON error record -- same leading keys as the bench line, value null -- and the
+    process leaves with exit code 3, from the watchdog's thread (the main thread never returns); a phase that ends in time leaves no trace."""
+    import subprocess
+    code = ("import sys, time; sys.path.insert(0, %r)\n"
+            "import bench\n"
+            "w = bench.Watchdog(0, 2, 2)\n"
+            "w.arm('quick phase', 5.0); w.disarm()\n"
+            "w.arm('rendezvous that never completes', 0.5)\n"
+            "time.sleep(30)\n"
+            "print('NOT REACHED')\n" % ROOT)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=25)
+    assert p.returncode == 3, (p.returncode, p.stderr[-300:])
+    assert "NOT REACHED" not in p.stdout
+    rec = json.loads(p.stdout.strip().splitlines()[-1])
+    assert rec["value"] is None and rec["n_gpus"] == 2 and "rendezvous that never completes" in rec["error"] and rec["metric"] == "Mrays/s"
+    # a rank other than 0 leaves as loudly, without a record
+    p = subprocess.run([sys.executable, "-c", code.replace("Watchdog(0, 2, 2)", "Watchdog(1, 2, 2)")], capture_output=True, text=True, timeout=25)
+    assert p.returncode == 3 and p.stdout.strip() == "" and "giving up" in p.stderr
