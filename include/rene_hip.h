@@ -327,6 +327,19 @@ int rene_get_stats(rene_ctx* ctx, rene_stats* out);
 int rene_trace(rene_ctx* ctx, int which, size_t n, const float* origins, const float* directions,
                float tmin, float tmax, rene_hit* out);
 
+/* The J1 gate (probes, no reference counterpart): what does traversal alone cost when its rays come from a queue?
+ * rene_ray_dump renders frames [first_frame, first_frame + n_frames) on a RENE_FLAG_COUNTERS context of a deep-BVH path-integrator scene and
+ * records every traversal query the launch issues -- 8 floats per ray: o.xyz, tmax, d.xyz, bits(pixel | depth << 21 | any-hit << 27 | emitter
+ * structure << 28 | (frame & 7) << 29) -- up to `capacity` rays into host memory; *n_issued = the queries issued (may exceed capacity).  The frames are accumulated
+ * like any rendered frames.  rene_trace_queue runs a traversal-only persistent pass over n rays in queue order (origin + tmax as 4 floats; the
+ * direction as three halves + flags in the fourth half (fp16 != 0, 8 bytes per ray) or three floats + flags (16 bytes); flag bit 0 any-hit,
+ * bit 1 emitter-only structure): free lanes are refilled from the queue as soon as `refill_min` of a wave's 64 are free; `repeats` timed
+ * launches, *ms = the fastest; hits4 (optional): t (-1 = miss), u, v, bits(slot) per ray; steps5 (optional): wave-steps and lane-steps of the
+ * node and leaf steps + iterations. */
+int rene_ray_dump(rene_ctx* ctx, uint32_t first_frame, uint32_t n_frames, size_t capacity, float* rays8, uint64_t* n_issued);
+int rene_trace_queue(rene_ctx* ctx, size_t n, const float* o_tmax4, const void* d_flags, int fp16, uint32_t refill_min, uint32_t leaf_min,
+                     uint32_t blocks_per_cu, uint32_t repeats, float* hits4, float* ms, uint64_t* steps5);
+
 /* Per-function probe of the device BSDF code (EnumMaterial::compute_bsdf + Bsdf::{f, pdf, sample_f},
  * rene-shader/src/material.rs:739-769, reflection.rs:286-342): for each of the n items builds the
  * lobes of `material_index` at (normal, uv) and writes 12 floats: f(wo,wi).rgb, pdf(wo,wi),

@@ -147,7 +147,7 @@ def algorithmic_bytes(stats) -> int:
 # every symbol include/rene_hip.h declares (tests check that the shared library exports them all)
 EXPORTED_SYMBOLS = [
     "rene_create", "rene_render", "rene_sync", "rene_download", "rene_reset", "rene_tune", "rene_framebuffer",
-    "rene_get_stats", "rene_trace", "rene_bsdf_eval", "rene_medium_eval", "rene_emitter_pdf", "rene_pcg_probe",
+    "rene_get_stats", "rene_trace", "rene_ray_dump", "rene_trace_queue", "rene_bsdf_eval", "rene_medium_eval", "rene_emitter_pdf", "rene_pcg_probe",
     "rene_comm_unique_id", "rene_comm_init", "rene_comm_init_all", "rene_comm_group_begin", "rene_comm_group_end",
     "rene_reduce", "rene_gather_tiles", "rene_destroy", "rene_scene_pack_info", "rene_last_error", "rene_abi_version",
     "rene_to_rgb8", "rene_to_aov8", "rene_frame_seeds",

@@ -64,6 +64,8 @@ def lib():
     L.rene_medium_eval.argtypes = [vp, u32, C.c_size_t, vp, vp, vp, vp, vp, vp]
     L.rene_emitter_pdf.argtypes = [vp, C.c_size_t, vp, vp, vp]
     L.rene_pcg_probe.argtypes = [i32, u32, u32, vp]
+    L.rene_ray_dump.argtypes = [vp, u32, u32, C.c_size_t, vp, C.POINTER(C.c_uint64)]
+    L.rene_trace_queue.argtypes = [vp, C.c_size_t, vp, vp, i32, u32, u32, u32, u32, vp, C.POINTER(C.c_float), vp]
     L.rene_comm_unique_id.argtypes = [vp]
     L.rene_comm_init.argtypes = [vp, i32, i32, vp]
     L.rene_comm_init_all.argtypes = [C.POINTER(vp), i32]
@@ -190,6 +192,32 @@ def _emitter_pdf(self, origins, directions) -> np.ndarray:
 
 
 Renderer.emitter_pdf = _emitter_pdf
+
+
+def _ray_dump(self, first_frame: int, n_frames: int, capacity: int):
+    """(rays [n][8] f32 -- o.xyz, tmax, d.xyz, meta bits --, queries issued) of the frames rendered: rene_ray_dump (the J1 gate's input)."""
+    out = np.zeros((capacity, 8), np.float32)
+    n = C.c_uint64()
+    _check(lib().rene_ray_dump(self._h, first_frame, n_frames, capacity, out.ctypes.data_as(C.c_void_p), C.byref(n)))
+    return out[:min(capacity, n.value)], n.value
+
+
+def _trace_queue(self, o_tmax, d_flags, fp16: bool, refill_min: int = 16, leaf_min: int = 6, blocks_per_cu: int = 0, repeats: int = 3,
+                 want_hits: bool = False, want_steps: bool = True):
+    """rene_trace_queue: (milliseconds of the fastest launch, hits [n][4] or None, steps5 or None)."""
+    o = np.ascontiguousarray(o_tmax, np.float32)
+    d = np.ascontiguousarray(d_flags)
+    n = o.shape[0]
+    hits = np.zeros((n, 4), np.float32) if want_hits else None
+    steps = np.zeros(5, np.uint64) if want_steps else None
+    ms = C.c_float()
+    p = lambda x: x.ctypes.data_as(C.c_void_p) if x is not None else None
+    _check(lib().rene_trace_queue(self._h, n, p(o), p(d), int(fp16), refill_min, leaf_min, blocks_per_cu, repeats, p(hits), C.byref(ms), p(steps)))
+    return ms.value, hits, steps
+
+
+Renderer.ray_dump = _ray_dump
+Renderer.trace_queue = _trace_queue
 
 
 def _comm_init(self, n_ranks: int, rank: int, unique_id: bytes):

@@ -58,6 +58,8 @@ hipError_t launch_pcg_probe(uint32_t seed, uint32_t n, uint32_t* out, hipStream_
 // buffer [owned tile][layer][32][32][4] (out-of-image texels of edge tiles are zero / skipped)
 hipError_t launch_pack_tiles(const float* fb, float* packed, uint32_t width, uint32_t height, uint32_t tiles_x, uint32_t n_tiles,
                              uint32_t shard_rank, uint32_t shard_count, bool unpack, hipStream_t st);
+// rene_trace_queue (probe, kernels_gate.hip): a traversal-only persistent pass over a queue-ordered ray buffer; step_counters (optional): 5 x u64
+hipError_t launch_trace_queue(const LaunchConfig& cfg, const SceneView& S, const TraceQueue& Q, uint32_t blocks_per_cu, unsigned long long* step_counters, hipStream_t st);
 // frame chains: out[3][H][W][4] = the CHAINS images of `chains` added in chain order (alpha 0); the chains are left as they are
 hipError_t launch_resolve_chains(const float* chains, float* out, size_t image_floats, hipStream_t st);
 // the same over the tiles a tile shard owns (tile t with t % shard_count == shard_rank); zero = true: clears the chains there instead

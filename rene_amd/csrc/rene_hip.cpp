@@ -202,6 +202,8 @@ struct rene_ctx {
   // the caller's -- is the image handed out: the chains added in chain order whenever a drain finds launches since the last one (`fb_stale`)
   float* chains = nullptr;
   bool fb_stale = false;
+  float* ray_dump = nullptr;     // rene_ray_dump in progress: where the counting restart kernel records its queries
+  uint32_t ray_dump_cap = 0;
   static constexpr uint32_t kCounters = 60;  // launches between two drains: each takes its own zeroed work counter
   uint32_t* d_work_counters = nullptr;        // [kCounters]
   unsigned long long* d_wave_times = nullptr; // RENE_DEBUG: [kCounters][8192][2]
@@ -764,6 +766,8 @@ static int rene_render_impl(rene_ctx* c, uint32_t first_frame, uint32_t n_frames
   P.work_counter = work_counter;
   P.wave_times = c->d_wave_times ? c->d_wave_times + (size_t)c->counters_used * 8192 * 2 : nullptr;
   P.item_done = c->d_item_done;
+  P.ray_dump = c->ray_dump;
+  P.ray_dump_cap = c->ray_dump_cap;
   P.counters = c->d_counters;
   P.n_frames = my_count;
   // frame chains (device_scene.h): global frame f belongs to chain (f / frame_stride) % CHAINS -- a rule on the frame's number, so that a pixel's
@@ -1111,6 +1115,88 @@ int rene_trace(rene_ctx* c, int which, size_t n, const float* origins, const flo
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   cleanup();
   if (e != hipSuccess) return fail(RENE_ERR_DEVICE, std::string("rene_trace: ") + hipGetErrorString(e));
+  return RENE_OK;
+}
+
+// ---- the J1 gate (probes; DESIGN.md section 9, tools/j1_gate.py) ---------------------------------------------------------------------------------
+int rene_ray_dump(rene_ctx* c, uint32_t first_frame, uint32_t n_frames, size_t capacity, float* rays8, uint64_t* n_issued) {
+  if (!c || !rays8 || !n_issued || capacity == 0 || capacity > 0x7fffffffull / 8) return fail(RENE_ERR_INVALID_ARGUMENT, "rene_ray_dump: bad argument");
+  if (!(c->opts.flags & RENE_FLAG_COUNTERS) || c->wavefront || (c->cfg.features & (rene::FEAT_SMALL | rene::FEAT_VOLPATH)) || (c->opts.flags & RENE_FLAG_NO_RESTART) ||
+      c->view.main.n_nodes <= 512u)
+    return fail(RENE_ERR_UNSUPPORTED, "rene_ray_dump: a context with RENE_FLAG_COUNTERS whose scene the traversal-restart kernel renders (path integrator, more than 512 BVH nodes)");
+  HIP_TRY(hipSetDevice(c->device));
+  int rc = c->drain();
+  if (rc != RENE_OK) return rc;
+  float* d = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), (capacity + 1) * 8 * sizeof(float)));
+  hipError_t e = c->zero_now(d, 8 * sizeof(float));
+  if (e != hipSuccess) { hipFree(d); return fail(RENE_ERR_DEVICE, std::string("rene_ray_dump: ") + hipGetErrorString(e)); }
+  c->ray_dump = d;
+  c->ray_dump_cap = (uint32_t)capacity;
+  rc = rene_render(c, first_frame, n_frames);
+  if (rc == RENE_OK) rc = c->drain();
+  c->ray_dump = nullptr;
+  c->ray_dump_cap = 0;
+  uint32_t issued = 0;
+  if (rc == RENE_OK) {
+    e = hipMemcpy(&issued, d, sizeof(issued), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(rays8, d + 8, std::min<size_t>(issued, capacity) * 8 * sizeof(float), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = fail(RENE_ERR_DEVICE, std::string("rene_ray_dump: ") + hipGetErrorString(e));
+  }
+  hipFree(d);
+  *n_issued = issued;
+  return rc;
+}
+
+int rene_trace_queue(rene_ctx* c, size_t n, const float* o_tmax4, const void* d_flags, int fp16, uint32_t refill_min, uint32_t leaf_min, uint32_t blocks_per_cu,
+                     uint32_t repeats, float* hits4, float* ms_out, uint64_t* steps5) {
+  if (!c || !n || !o_tmax4 || !d_flags || n > 0x7fffffffull) return fail(RENE_ERR_INVALID_ARGUMENT, "rene_trace_queue: bad argument");
+  if (c->cfg.features & rene::FEAT_SMALL) return fail(RENE_ERR_UNSUPPORTED, "rene_trace_queue: BVH scenes only");
+  HIP_TRY(hipSetDevice(c->device));
+  int rc = c->drain();
+  if (rc != RENE_OK) return rc;
+  float *d_o = nullptr, *d_h = nullptr;
+  uint32_t *d_d = nullptr, *d_cnt = nullptr;
+  unsigned long long* d_steps = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  auto cleanup = [&]() {
+    hipFree(d_o); hipFree(d_h); hipFree(d_d); hipFree(d_cnt); hipFree(d_steps);
+    if (ev0) hipEventDestroy(ev0);
+    if (ev1) hipEventDestroy(ev1);
+  };
+  const size_t dbytes = n * (fp16 ? 8 : 16);
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_o), n * 16);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_d), dbytes);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_h), n * 16);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_cnt), 64 * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_steps), 8 * sizeof(unsigned long long));
+  if (e == hipSuccess) e = hipMemcpy(d_o, o_tmax4, n * 16, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_d, d_flags, dbytes, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipEventCreate(&ev0);
+  if (e == hipSuccess) e = hipEventCreate(&ev1);
+  float best_ms = 0.0f;
+  for (uint32_t k = 0; e == hipSuccess && k < std::max(1u, repeats); ++k) {
+    e = c->zero_now(d_cnt, 64 * sizeof(uint32_t));
+    if (e == hipSuccess) e = c->zero_now(d_steps, 8 * sizeof(unsigned long long));
+    rene::TraceQueue Q{};
+    Q.o_tmax = d_o; Q.d_flags = d_d; Q.hits = d_h; Q.counter = d_cnt; Q.n = (uint32_t)n;
+    Q.refill_min = std::max(1u, std::min(64u, refill_min)); Q.leaf_min = std::max(1u, leaf_min); Q.fp16 = fp16 ? 1u : 0u;
+    Q.stack_entries = c->cfg.stack_depth;
+    Q.passes = 1;
+    if (const char* ev = std::getenv("RENE_GATE_PASSES")) Q.passes = (uint32_t)std::max(1, std::min((int)(0x7fffffffull / n), std::atoi(ev)));  // (probe knob: a longer launch)
+    if (e == hipSuccess) e = hipEventRecord(ev0, c->stream);
+    if (e == hipSuccess) e = rene::launch_trace_queue(c->cfg, c->view, Q, blocks_per_cu, steps5 ? d_steps : nullptr, c->stream);
+    if (e == hipSuccess) e = hipEventRecord(ev1, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    float ms = 0.0f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, ev0, ev1);
+    if (k == 0 || ms < best_ms) best_ms = ms;
+  }
+  if (e == hipSuccess && hits4) e = hipMemcpy(hits4, d_h, n * 16, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && steps5) e = hipMemcpy(steps5, d_steps, 5 * sizeof(uint64_t), hipMemcpyDeviceToHost);
+  cleanup();
+  if (e != hipSuccess) return fail(RENE_ERR_DEVICE, std::string("rene_trace_queue: ") + hipGetErrorString(e));
+  if (ms_out) *ms_out = best_ms;
   return RENE_OK;
 }
 
