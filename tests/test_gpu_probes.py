@@ -91,3 +91,42 @@ def test_veach_mis_without_the_small_light_is_tight(oracle_mod):
     for flags in (0, abi.FLAG_FORCE_BVH):
         sg, so = _compare(s, 16, oracle_mod, frac=2e-2, relmse=1e-4, ctol=2e-3, flags=flags)
         assert sg["rays_emitter"] > 0
+
+
+def test_ray_dump_and_the_queue_traversal_pass_agree_with_rene_trace():
+    """The J1 gate's two probes (include/rene_hip.h; tools/j1_gate.py, profiles/r04_j1_gate.txt): rene_ray_dump records every query the traversal-restart
+    kernel issues -- as many as the device counters count, every record a ray of the frames asked for -- and rene_trace_queue, the traversal-only persistent
+    pass over a queue (free lanes refilled from the queue, fp32 or fp16 direction payload), finds for every closest-hit ray the hit rene_trace finds and
+    for every any-hit ray the same verdict."""
+    import numpy as np
+    from rene_amd import abi, api, scenes
+    s = scenes.dragon_class(160, 90, 40, 44)
+    with api.Renderer(s, flags=abi.FLAG_COUNTERS) as r:
+        rays, issued = r.ray_dump(0, 2, 160 * 90 * 2 * 8)
+        st = r.stats().as_dict()
+        assert issued == len(rays) == st["rays"] and st["paths"] == 160 * 90 * 2
+        meta = rays[:, 7].view(np.uint32)
+        pix, depth, any_hit, frame = meta & 0x1FFFFF, (meta >> 21) & 63, (meta >> 27) & 1, (meta >> 29) & 7
+        assert pix.max() < 160 * 90 and set(np.unique(frame)) == {0, 1} and depth.max() < 50
+        assert int((any_hit == 0).sum()) == st["rays_closest"] and int(any_hit.sum()) == st["rays_shadow"]
+        assert ((depth == 0) & (any_hit == 0)).sum() == 160 * 90 * 2  # one camera ray per path
+        assert np.allclose(np.linalg.norm(rays[:, 4:7], axis=1), 1.0, atol=1e-4)
+        o_tmax = np.ascontiguousarray(rays[:, :4])
+        flags = any_hit.astype(np.uint32)
+        d32 = np.ascontiguousarray(np.concatenate([rays[:, 4:7], flags.view(np.float32)[:, None]], axis=1))
+        ref = r.trace(rays[:, :3], rays[:, 4:7], 0.001, 1e5, 0)
+        for refill in (1, 16, 64):
+            ms, hits, steps = r.trace_queue(o_tmax, d32, False, refill, 6, 0, 1, True, True)
+            closest = any_hit == 0
+            miss_q, miss_r = hits[:, 0] < 0, ref["t"] < 0
+            # shadow queries carry tmax 1e5 too (a distant light): the closest hit exists iff any hit does
+            assert np.array_equal(miss_q, miss_r), refill
+            ok = miss_q | (hits[:, 0] == ref["t"])
+            assert ok[closest].all(), refill
+            assert steps[1] > 0 and steps[3] > 0 and steps[1] <= 64 * steps[0]
+        h = rays[:, 4:7].astype(np.float16).view(np.uint16).astype(np.uint32)
+        d16 = np.ascontiguousarray(np.stack([h[:, 0] | (h[:, 1] << 16), h[:, 2] | (flags << 16)], axis=1).astype(np.uint32))
+        ms, hits16, _ = r.trace_queue(o_tmax, d16, True, 16, 6, 0, 1, True, False)
+        both = (hits16[:, 0] > 0) & (ref["t"] > 0) & (any_hit == 0)
+        assert ((hits16[:, 0] < 0) == (ref["t"] < 0)).mean() > 0.995  # a direction rounded to 11 bits moves a ray by 1e-3 of its length
+        assert np.median(np.abs(hits16[both, 0] - ref["t"][both]) / ref["t"][both]) < 2e-3
