@@ -341,19 +341,5 @@ struct RenderParams {
   uint32_t ray_dump_cap;
 };
 
-// rene_trace_queue (probe: the J1 gate): a traversal-only persistent pass over a queue-ordered SoA ray buffer
-struct TraceQueue {
-  const float* o_tmax;      // [n][4] origin, tmax
-  const uint32_t* d_flags;  // [n][2] direction as three halves + flags in the fourth (bit 0: any-hit, bit 1: emitter-only structure) -- or,
-                            // fp32 payload, [n][4] direction as three floats + flags
-  float* hits;              // [n][4] t (-1: miss), u, v, bits(slot)
-  uint32_t* counter;        // next ray of the queue (zeroed by the host)
-  uint32_t n;
-  uint32_t refill_min;      // dead lanes a wave gathers before it fetches rays for them (64: only when the whole wave is done)
-  uint32_t leaf_min;        // lanes at a leaf before the leaf step runs
-  uint32_t fp16;            // direction payload: 1 = three halves (8 bytes), 0 = three floats (16 bytes)
-  uint32_t stack_entries;
-  uint32_t passes;          // the queue is traversed this many times over in one launch (>= 1)
-};
 
 }  // namespace rene

@@ -58,6 +58,20 @@ hipError_t launch_pcg_probe(uint32_t seed, uint32_t n, uint32_t* out, hipStream_
 // buffer [owned tile][layer][32][32][4] (out-of-image texels of edge tiles are zero / skipped)
 hipError_t launch_pack_tiles(const float* fb, float* packed, uint32_t width, uint32_t height, uint32_t tiles_x, uint32_t n_tiles,
                              uint32_t shard_rank, uint32_t shard_count, bool unpack, hipStream_t st);
+// rene_trace_queue (probe: the J1 gate): a traversal-only persistent pass over a queue-ordered SoA ray buffer
+struct TraceQueue {
+  const float* o_tmax;      // [n][4] origin, tmax
+  const uint32_t* d_flags;  // [n][2] direction as three halves + flags in the fourth (bit 0: any-hit, bit 1: emitter-only structure) -- or,
+                            // fp32 payload, [n][4] direction as three floats + flags
+  float* hits;              // [n][4] t (-1: miss), u, v, bits(slot)
+  uint32_t* counter;        // next ray of the queue (zeroed by the host)
+  uint32_t n;
+  uint32_t refill_min;      // dead lanes a wave gathers before it fetches rays for them (64: only when the whole wave is done)
+  uint32_t leaf_min;        // lanes at a leaf before the leaf step runs
+  uint32_t fp16;            // direction payload: 1 = three halves (8 bytes), 0 = three floats (16 bytes)
+  uint32_t stack_entries;
+  uint32_t passes;          // the queue is traversed this many times over in one launch (>= 1)
+};
 // rene_trace_queue (probe, kernels_gate.hip): a traversal-only persistent pass over a queue-ordered ray buffer; step_counters (optional): 5 x u64
 hipError_t launch_trace_queue(const LaunchConfig& cfg, const SceneView& S, const TraceQueue& Q, uint32_t blocks_per_cu, unsigned long long* step_counters, hipStream_t st);
 // frame chains: out[3][H][W][4] = the CHAINS images of `chains` added in chain order (alpha 0); the chains are left as they are
