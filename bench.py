@@ -7,7 +7,7 @@ fixed spp; achieved rate against the roofline that binds).
 Headline workload: BASELINE.json configs[1], "Cornell-box 1024x1024 @ 1024 spp, 1x MI355X" (synthetic
 Cornell-box-shaped scene built in code, rene_amd/scenes.py).  A *step* is one whole such job: clear the
 accumulation image (rene/src/main.rs:1229-1237), render all 1024 frames of every pixel -- ONE launch of the persistent
-kernel, every pixel's frames cut into short work items -- and wait for it.  The K timed steps are K
+kernel, every pixel's frames cut into short work items (docs/history.md section 4f) -- and wait for it.  The K timed steps are K
 jobs back to back, each timed on its own as well: `step_ms_median` / `step_ms_min`.  Every job renders the same frames,
 so its image must be bit-identical to the first one's -- checked after the timed region.  Inputs (scene tables, BVH) are
 resident in HBM before the timed region; `value` = rays of all K jobs / elapsed.
@@ -176,7 +176,7 @@ def run_config(name: str, device: int = 0):
             return dt, rr.stats(), rr.download(0)
     # One job, the library's default path.  (Round 3 timed the BVH configurations twice -- strict frame order and, opt-in, two chains of
     # frames per pixel; since round 4 every context renders a pixel's frames as eight chains, frame f in chain f % 8, and the image is
-    # cut-independent: there is one mode.  DESIGN.md section 4f.)
+    # cut-independent: there is one mode.  docs/history.md section 4f.)
     dt, s2, im = job(0)
     assert bool(np.isfinite(im).all()) and float(im.mean()) > 0.0, f"{name}: image empty or non-finite"
     rl2 = rooflines(name, s2.rays / dt, cus, bpr, s2.sclk_mhz or None)

@@ -204,7 +204,7 @@ enum {
                                  two streams so that one started while the previous drained its longest paths.  One launch now
                                  renders any number of frames in short work items, so a job is ONE rene_render call with no tail
                                  between launches to hide, and no launch ever waits for another: the occasional stall of the
-                                 two-stream scheme -- DESIGN.md section 4g -- has nothing left to come from.) */
+                                 two-stream scheme -- docs/history.md section 4g -- has nothing left to come from.) */
   ,
   RENE_FLAG_FRAME_GROUPS = 1u << 9 /* accepted and ignored since ABI v5: what it asked for is how every context renders.  A pixel's frames are
                                       EIGHT independent chains -- global frame f belongs to chain f % 8 (under RENE_SHARD_FRAMES: (f / shard_count) % 8),

@@ -159,7 +159,7 @@ Rccl* rccl() {
 
 // Host-side waits poll (hipEventQuery / hipStreamQuery read the completion signal) instead of blocking in the runtime: a
 // blocked wait depends on a wake-up from the driver, and on this pool a job of many launches was seen to sit in
-// one for minutes now and then; polling costs one host thread a few microseconds of latency.
+// one for minutes now and then (docs/history.md section 4g); polling costs one host thread a few microseconds of latency.
 static hipError_t wait_event(hipEvent_t ev) {
   const auto t0 = std::chrono::steady_clock::now();
   int told = 0;
@@ -291,7 +291,7 @@ struct rene_ctx {
   // Zeroes device memory and WAITS for it.  (hipMemset on the null stream returns before the fill has run -- it is a kernel, and
   // behind a persistent launch on another queue it gets a slot only when that launch's first waves leave: the work counters
   // of launches already running were then zeroed under them, their ids handed out a second time, and the duplicates waited
-  // for versions that had passed.  DESIGN.md section 4g.)
+  // for versions that had passed.  docs/history.md section 4g.)
   hipError_t zero_now(void* p, size_t bytes) {
     hipError_t e = hipMemsetAsync(p, 0, bytes, stream);
     return e == hipSuccess ? wait_stream(stream) : e;
@@ -746,7 +746,7 @@ static int rene_render_impl(rene_ctx* c, uint32_t first_frame, uint32_t n_frames
   // Launches are serial on the context's one stream.  (Rounds 1-2 alternated consecutive launches between two streams so that
   // the next launch filled the slots the previous one's tail vacated; the waves of the later launch then waited, holding
   // their slots, for pixels of the earlier one -- and when the driver evicted and restored the process's queues, the earlier
-  // launch's waves could find their slots taken: a stall of seconds, DESIGN.md section 4g.  One launch per job in short work
+  // launch's waves could find their slots taken: a stall of seconds, docs/history.md section 4g.  One launch per job in short work
   // items has the same tail to hide -- none between launches -- and no launch ever waits for another.)
   hipStream_t stream = c->stream;
   uint32_t* work_counter = c->d_work_counters + c->counters_used;
@@ -799,7 +799,7 @@ static int rene_render_impl(rene_ctx* c, uint32_t first_frame, uint32_t n_frames
     // (measured, one launch per job, MI355X: Cornell 1024 frames flat from 64 to 96 frames per item, veach-mis 4096 frames best at
     // 256 - 341, dragon-class 1024 at 32, the teapot scene 8192 at 256: it is the number of item switches per pixel that a launch
     // pays for, and the length of its last item -- and a BVH scene's pixels differ more in cost);
-    // no halving tail by default (tail = item): it buys nothing once the hand-off waits are rare
+    // no halving tail by default (tail = item): it buys nothing once the hand-off waits are rare (docs/history.md section 4f)
     // (short launches -- one rank's share of a multi-GPU job -- want few, long items: Cornell 128 frames, 8 / 16 / 32 / 64 frames per
     // item: 6.89 / 6.59 / 6.59 / 6.41 ms; 256 frames, 16 / 32 / 64 / 128: 13.30 / 13.13 / 13.21 / 12.84; 512 frames, 32 / 64 / 128: 24.93 / 24.74 / 25.23)
     // (frame groups: a chain has half the frames and wants items as long as the undivided job's, or longer -- dragon-class, two chains of 512
@@ -905,7 +905,7 @@ static int rene_render_impl(rene_ctx* c, uint32_t first_frame, uint32_t n_frames
   const uint32_t waves = cfg.grid * (uint32_t)(rene::render_block_size() / 64);
   // 64 ids = one wave's worth: every id a wave takes is rendered at once.  (With 128 the second half of a batch sat reserved
   // until lanes of that wave came free, its pixels started late, and the items that continue from them -- handed out one sweep
-  // of the image later -- found them unfinished: Cornell 52.1 -> 48.5 ms per job)
+  // of the image later -- found them unfinished: Cornell 52.1 -> 48.5 ms per job, docs/history.md section 4f.)
   P.work_batch = 64;
   if (const char* e = std::getenv("RENE_WORK_BATCH")) P.work_batch = (uint32_t)std::max(16, std::min(1024, std::atoi(e)));  // tuning knob
   while (P.work_batch > 16 && (uint64_t)P.work_batch * waves * 2u > total_items) P.work_batch >>= 1;

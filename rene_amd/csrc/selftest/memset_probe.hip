@@ -1,5 +1,5 @@
 // memset_probe.hip -- is hipMemset (null stream, device memory) complete when it returns, while a persistent kernel on a
-// non-blocking stream holds every CU slot?  (the question behind rene_ctx::zero_now)
+// non-blocking stream holds every CU slot?  (the question behind rene_ctx::zero_now, docs/history.md section 4g)
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>

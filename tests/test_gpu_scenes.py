@@ -390,7 +390,7 @@ def test_instance_and_light_tables_in_lds_are_bit_identical(monkeypatch, name):
 
 def test_soak_many_launches_none_replayed():
     """rounds 1-2 overlapped consecutive launches on two streams and now and then a launch stalled for
-    seconds behind the next one's waiters; launches are serial now and no launch waits for another.
+    seconds behind the next one's waiters (docs/history.md section 4g); launches are serial now and no launch waits for another.
     Thirty jobs of sixteen launches each at full size on rene's teapot scene: every launch issued is a launch counted --
     none dropped a work item and had to be launched again -- and every job's image equals the first one's, bit for bit."""
     s = scenes.teapot_full(1920, 1080)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Is a BVH job bound by its heaviest pixel's chain of frames?  (a pixel's frames are rendered one after the other,
+"""Is a BVH job bound by its heaviest pixel's chain of frames?  (docs/history.md section 4f: a pixel's frames are rendered one after the other,
 so that the sums are added in the reference's order; the job cannot end before its most expensive pixel has gone through all of them.)
 Renders one job of a bench configuration (a) as one context, one launch, and (b) as G contexts on the same GPU, context g rendering the
 frames f with f % G == g into an image of its own, each launch sized to 1 / G of the chip's workgroup slots (RENE_BLOCKS_PER_CU) so that
