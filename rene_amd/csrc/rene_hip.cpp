@@ -582,7 +582,13 @@ static int rene_create_impl(const rene_scene_desc* scene, const rene_opts* opts,
   uint32_t stack = 16;
   while (stack < depth) stack += 4;  // 40 entries x 1024 lanes x 4 B = the whole 160 KB of a CU at 4 waves per SIMD
   if (stack > 96) return fail(RENE_ERR_UNSUPPORTED, "BVH deeper than the 96-entry traversal stack");
-  if (const char* e = std::getenv("RENE_STACK_ENTRIES")) stack = (uint32_t)std::max(8, std::atoi(e));  // occupancy EXPERIMENTS only: unchecked
+  // (occupancy experiments: RENE_STACK_ENTRIES may only GROW the stack -- a stack shallower than the tree's worst case would let a deep query write
+  // past its column into other lanes' entries and the LDS tables: refused)
+  if (const char* e = std::getenv("RENE_STACK_ENTRIES")) {
+    const int want = std::atoi(e);
+    if (want < (int)depth) return fail(RENE_ERR_INVALID_ARGUMENT, "RENE_STACK_ENTRIES is below the traversal stack this scene's BVH can need (" + std::to_string(depth) + " entries)");
+    stack = (uint32_t)std::min(96, want);
+  }
   c->cfg.features = ps.features;
   if (o.flags & RENE_FLAG_FORCE_BVH) c->cfg.features &= ~rene::FEAT_SMALL;
   c->cfg.stack_depth = stack;

@@ -47,6 +47,8 @@ def test_production_variants_keep_their_occupancy(hip_lib):
     # (first-hit layers on, counters off) variants: FEAT 72 = Matte small-scene kernel (the bench kernel), 95 = general
     # single-lobe small-scene kernel, 8 / 31 = Matte / general traversal-restart kernels
     assert one("render_kernelILj72ELi1ELb0ELb1")["occupancy"] >= 5 and one("render_kernelILj72ELi1ELb0ELb1")["scratch"] == 0
+    k = one("render_kernelILj64ELi1ELb0ELb1")  # Cornell's (no distant lights): the bench kernel, six waves per SIMD
+    assert k["occupancy"] >= 6 and k["vgpr"] <= 80 and k["scratch"] == 0 and k["sgpr_spill"] <= 1
     assert one("render_kernelILj95ELi1ELb0ELb1")["occupancy"] >= 3 and one("render_kernelILj95ELi1ELb0ELb1")["scratch"] == 0
     # (the restart kernels come with the instance / light tables in global memory, ...Lb0E, or in LDS, ...Lb1E)
     for tables in ("Lb0E", "Lb1E"):
@@ -54,9 +56,11 @@ def test_production_variants_keep_their_occupancy(hip_lib):
         assert one("render_kernel_wfILj31ELi1ELb0ELb1E" + tables)["occupancy"] >= 3 and one("render_kernel_wfILj31ELi1ELb0ELb1E" + tables)["scratch"] == 0
         assert one("render_kernel_wfILj1302ELi1ELb0ELb1E" + tables)["occupancy"] >= 4 and one("render_kernel_wfILj1302ELi1ELb0ELb1E" + tables)["scratch"] == 0  # Substrate-only
         # ... and the two bench scenes' instantiations, without the emitter mixture (FEAT_NO_EMITTERS = 2048): 8 | 2048, 1302 | 2048
-        assert one("render_kernel_wfILj2056ELi1ELb0ELb1E" + tables)["occupancy"] >= 4 and one("render_kernel_wfILj2056ELi1ELb0ELb1E" + tables)["vgpr"] <= 128  # (116 with the light share of the last-light fast path: still four waves)
+        # (pinned at the measured values, ADVICE r3: the dragon-class kernel 110 VGPRs and no spill, the teapot kernel 128 VGPRs and six SGPR spills)
+        k = one("render_kernel_wfILj2056ELi1ELb0ELb1E" + tables)
+        assert k["occupancy"] >= 4 and k["vgpr"] <= 112 and k["sgpr_spill"] == 0 and k["scratch"] == 0
         k = one("render_kernel_wfILj3350ELi1ELb0ELb1E" + tables)
-        assert k["occupancy"] >= 4 and k["scratch"] == 0 and k["sgpr_spill"] <= 8  # (six with the frame-group bookkeeping of the item switch; the job times of the default mode did not move)
+        assert k["occupancy"] >= 4 and k["scratch"] == 0 and k["sgpr_spill"] <= 6 and k["vgpr"] <= 128
     # multi-lobe kernels: two waves (they were at one, with 376 bytes of scratch per lane)
     assert one("render_kernelILj127ELi5ELb0ELb1")["occupancy"] >= 2
     # traversal passes of the wavefront integrator are register-light by construction

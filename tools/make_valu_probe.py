@@ -46,6 +46,28 @@ OPS = [
 ]
 
 
+# second set (round 4, `make_valu_probe.py decode`): candidates for a cheaper BVH4 node decode -- what turns a quantised child plane into a float, and
+# the packed / half-precision forms of the slab test's arithmetic
+OPS_DECODE = [
+    ("v_cvt_f32_ubyte1_e32", "v_cvt_f32_ubyte1_e32 %A, %A"), ("v_cvt_f32_ubyte3_e32", "v_cvt_f32_ubyte3_e32 %A, %A"),
+    ("v_cvt_f32_f16_e32", "v_cvt_f32_f16_e32 %A, %A"),
+    ("v_fma_mix_f32 (f16 lo, f32, f32)", "v_fma_mix_f32 %A, %B, %C, %A op_sel_hi:[1,0,0]"),
+    ("v_fma_mix_f32 (f16 hi, f32, f32)", "v_fma_mix_f32 %A, %B, %C, %A op_sel:[1,0,0] op_sel_hi:[1,0,0]"),
+    ("v_fma_mix_f32 (all f32)", "v_fma_mix_f32 %A, %B, %C, %A"),
+    ("v_pk_fma_f16", "v_pk_fma_f16 %A, %A, %B, %C"), ("v_pk_mul_f32", "v_pk_mul_f32 %P, %P, %Q"), ("v_pk_add_f32", "v_pk_add_f32 %P, %P, %Q"),
+    ("v_pk_max_f16", "v_pk_max_f16 %A, %A, %B"), ("v_pk_min_f16", "v_pk_min_f16 %A, %A, %B"),
+    ("v_perm_b32", "v_perm_b32 %A, %A, %B, %C"), ("v_dot2_f32_f16", "v_dot2_f32_f16 %A, %B, %C, %A"),
+    ("v_or_b32_sdwa (byte1)", "v_or_b32_sdwa %A, %A, %B dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1"),
+    ("v_and_b32_sdwa (byte2)", "v_and_b32_sdwa %A, %A, %B dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2"),
+    ("v_add_u32_sdwa (byte3)", "v_add_u32_sdwa %A, %A, %B dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3"),
+    ("v_cvt_f32_u32_sdwa (byte1)", "v_cvt_f32_u32_sdwa %A, %A dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1"),
+    ("v_mul_f32_sdwa (word1)", "v_mul_f32_sdwa %A, %A, %B dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"),
+    ("v_cvt_pk_f32_fp8_e32", "v_cvt_pk_f32_fp8_e32 %P, %B"), ("v_cvt_scalef32_pk_f32_fp8", "v_cvt_scalef32_pk_f32_fp8 %P, %B, %C"),
+    ("v_max_f16_e32", "v_max_f16_e32 %A, %A, %B"), ("v_alignbit_b32", "v_alignbit_b32 %A, %A, %B, 8"), ("v_mad_u32_u24", "v_mad_u32_u24 %A, %A, %B, %C"),
+    ("v_mul_u32_u24_e32", "v_mul_u32_u24_e32 %A, %A, %B"), ("v_or_b32_e32", "v_or_b32_e32 %A, %A, %B"), ("v_and_or_b32", "v_and_or_b32 %A, %A, %B, %C"),
+]
+
+
 def stmt(tpl, k):
     outs, ins = [], []
     t = tpl
@@ -73,6 +95,11 @@ def stmt(tpl, k):
 
 
 def main():
+    import sys
+    global OPS
+    which = sys.argv[1] if len(sys.argv) > 1 else "rates"
+    if which == "decode":
+        OPS = OPS_DECODE
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     body = []
     for n, (name, tpl) in enumerate(OPS):
@@ -134,7 +161,7 @@ int main() {{
   return 0;
 }}
 '''
-    open(os.path.join(root, "rene_amd", "csrc", "selftest", "valu_rate_probe.hip"), "w").write(src)
+    open(os.path.join(root, "rene_amd", "csrc", "selftest", "valu_rate_probe.hip" if which == "rates" else "valu_decode_probe.hip"), "w").write(src)
 
 
 if __name__ == "__main__":
