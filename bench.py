@@ -12,14 +12,15 @@ jobs back to back, each timed on its own as well: `step_ms_median` / `step_ms_mi
 so its image must be bit-identical to the first one's -- checked after the timed region.  Inputs (scene tables, BVH) are
 resident in HBM before the timed region; `value` = rays of all K jobs / elapsed.
 
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL).  STRONG scaling by default: the job stays the
-1024-spp image of the N = 1 line; its frames are dealt to the ranks in N contiguous blocks (rene_amd.dist.frame_block:
-128 frames per rank at N = 8, every rank keeps the whole image -- a million pixel chains -- in flight), ranks never talk
-while rendering, and the one exchange step of a job -- an RCCL reduce (sum) of the [3][H][W][4] f32 partial images onto
-rank 0 -- is inside the job, hence inside the timed region.  RENE_BENCH_SHARD=tiles selects north_star's cut instead
-(32x32 tiles round-robin + a gather of owned tiles: bit-identical to one GPU, but a rank's 131 k pixel chains at N = 8 do
-not fill its 393 k lanes; DESIGN.md section 6 has the measurement behind the default).  RENE_BENCH_SCALING=weak renders an
-N x 1024 spp image (1024 frames per rank).  value = rays of all ranks / max-over-ranks time.
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL).  STRONG scaling: the job stays the 1024-spp image of
+the N = 1 line.  Default since round 4: north_star's cut -- 32x32 pixel tiles round-robin over the ranks, every rank all 1024
+frames of its tiles (with a pixel's frames as eight chains an eighth of the image keeps a million work items in flight:
+0.87 - 0.89 render efficiency at N = 8 on one GPU's share), ranks never talk while rendering, and the one
+exchange step of a job -- rene_gather_tiles: every rank sends its 1 / N of the image to rank 0 -- is inside the job, hence
+inside the timed region; the image is bit-identical to the one-GPU render.  RENE_BENCH_SHARD=frames: contiguous frame blocks +
+an RCCL reduce (sum) of the [3][H][W][4] f32 partial images instead; with it RENE_BENCH_SCALING=weak renders an N x 1024 spp
+image.  value = rays of all ranks / max-over-ranks time.  A watchdog (class Watchdog) bounds every phase that can wait for
+another rank; on overrun rank 0 prints an error record and every rank exits 3.
 
 The JSON line also carries
   roofline     -- for the dominant kernel of the headline job.  The kernel is bound by VALU issue, not by HBM (the
@@ -35,7 +36,7 @@ The JSON line also carries
                   SURVEY 8d's cache-less algorithmic bytes for comparison (not a fraction of anything: the scene
                   lives in the caches).  `traffic` = measured HBM bytes per launch.
   configs      -- N > 1: BASELINE's 8-GPU configurations C4 (dragon-class 1920x1080 @ 1024 spp) and C5 (teapot-class 1920x1080 @ 8192 spp),
-                  one job each, sharded over the N ranks like the headline (frame blocks + one RCCL reduce), max-over-ranks time.
+                  one job each, sharded over the N ranks like the headline (tiles + one gather), max-over-ranks time.
                   N = 1: the other BASELINE configurations that fit one GPU, one full job each at its own
                   resolution and sample count (C3 veach-mis 1024x1024 @ 4096 spp, C4 dragon-class 1920x1080 @ 1024 spp,
                   C5 teapot-class 1920x1080 @ 8192 spp), each with rays, Mrays/s, ms/frame and the same two fractions.
@@ -47,6 +48,8 @@ The JSON line also carries
 from __future__ import annotations
 
 import argparse
+import os
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (multi-process GPU work on this pool: the host driver only supports dmabuf IPC)
 import json
 import math
 import os
