@@ -111,7 +111,8 @@ class Oracle:
          "jitter_w": 1 << 11, "light_pdf_area": 1 << 12, "tmin_1e4": 1 << 13, "cos_from_ng": 1 << 14, "pdf_faceforward": 1 << 15,
          "pdf_zero": 1 << 16}
 
-    def set_experiment(self, bits: int = 0, decomposition: bool = False, depth_cap: int = 0):
+    def set_experiment(self, bits: int = 0, decomposition=False, depth_cap: int = 0):
+        """decomposition: False / True (every layer-0 add kept by bounce and branch) / 2 (by bounce and by the instance the light branch was taken at)"""
         lib().oracle_set_experiment(self._h, (bits | (depth_cap << 24)) & 0xFFFFFFFF, int(decomposition))
 
     def download_decomposition(self, depth: int, branch: int) -> np.ndarray:

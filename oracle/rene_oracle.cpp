@@ -814,7 +814,10 @@ struct Scene {
   };
   uint32_t xbits = 0;
   static constexpr int DECOMP_DEPTHS = 10;  // add at bounce 0..8, 9 = deeper
-  std::vector<double> decomp;               // [DECOMP_DEPTHS][2 branches][H][W][3], empty = off
+  static constexpr int DECOMP_KEYS = 12;    // decomp_keys == 2: key = the branch (0 light, 1 BSDF); == DECOMP_KEYS: key = the INSTANCE at which the light branch
+                                            // that found the light was taken (0..10), 11 = found through a BSDF-branch ray
+  int decomp_keys = 2;
+  std::vector<double> decomp;               // [DECOMP_DEPTHS][decomp_keys][H][W][3], empty = off
 
   // ---- traversal (stands in for the Vulkan driver; lib.rs:195-207 etc.) ----
   bool intersect_instance(uint32_t ii, V3 o, V3 d, float tmin, float& tmax, Hit& hit, bool any,
@@ -1388,12 +1391,14 @@ struct Scene {
   void raygen(uint32_t x, uint32_t y, uint32_t seed, Counters& c) {
     int i = 0;
     int branch = 1;  // which branch chose the current ray: 0 light, 1 BSDF (the camera ray counts as BSDF)
+    int branch_inst = DECOMP_KEYS - 1;  // the instance at which that light branch was taken
     auto add_image = [&](uint32_t layer, V3 v) {  // lib.rs:165-172
       float* p = &image[(((size_t)layer * H + (H - 1 - y)) * W + x) * 4];
       p[0] = p[0] + v.x; p[1] = p[1] + v.y; p[2] = p[2] + v.z; p[3] = p[3] + 0.0f;
       c.adds++;
       if (layer == 0 && !decomp.empty()) {
-        size_t k = (size_t)std::min(i, DECOMP_DEPTHS - 1) * 2 + branch;
+        const int key = decomp_keys == 2 ? branch : (branch == 0 ? std::min(branch_inst, DECOMP_KEYS - 2) : DECOMP_KEYS - 1);
+        size_t k = (size_t)std::min(i, DECOMP_DEPTHS - 1) * decomp_keys + key;
         double* q = &decomp[((k * H + (H - 1 - y)) * W + x) * 3];
         q[0] += v.x; q[1] += v.y; q[2] += v.z;
       }
@@ -1463,6 +1468,7 @@ struct Scene {
             if (xbits & X_PDF_ZERO) pdf = 0.0f;
             f = bsdf.f(wo, wi);
             branch = 0;
+            branch_inst = (int)payload.index;
             if ((xbits & X_LIGHT_PDF_AREA) && eo.type == 0) pdf_l_sampled = sampled_point_pdf(eo, lp, position, wi);
           } else {
             SampledF s = bsdf.sample_f(wo, rng);
@@ -1675,15 +1681,16 @@ void oracle_destroy(oracle_ctx* c) { delete c; }
 // experiments (tools/cornell_offsets.py): `bits` = Scene::X_* switches; decomposition != 0 keeps every layer-0 add sorted by bounce and branch
 void oracle_set_experiment(oracle_ctx* c, uint32_t bits, int decomposition) {
   c->s.xbits = bits;
-  if (decomposition) c->s.decomp.assign((size_t)Scene::DECOMP_DEPTHS * 2 * c->s.W * c->s.H * 3, 0.0);
+  c->s.decomp_keys = decomposition == 2 ? Scene::DECOMP_KEYS : 2;  // 1: by branch, 2: by the instance the light branch was taken at
+  if (decomposition) c->s.decomp.assign((size_t)Scene::DECOMP_DEPTHS * c->s.decomp_keys * c->s.W * c->s.H * 3, 0.0);
   else c->s.decomp.clear();
 }
 // dst[H][W][3] f32: the adds of bounce `depth` (0..9, 9 = deeper) found through rays of `branch` (0 light, 1 BSDF)
 int oracle_download_decomposition(oracle_ctx* c, int depth, int branch, float* dst) {
   Scene& s = c->s;
-  if (s.decomp.empty() || depth < 0 || depth >= Scene::DECOMP_DEPTHS || branch < 0 || branch > 1) return -1;
+  if (s.decomp.empty() || depth < 0 || depth >= Scene::DECOMP_DEPTHS || branch < 0 || branch >= s.decomp_keys) return -1;
   size_t n = (size_t)s.W * s.H * 3;
-  const double* src = &s.decomp[((size_t)depth * 2 + branch) * n];
+  const double* src = &s.decomp[((size_t)depth * s.decomp_keys + branch) * n];
   for (size_t i = 0; i < n; ++i) dst[i] = (float)src[i];
   return 0;
 }

@@ -64,6 +64,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("npz", nargs="+")
     ap.add_argument("--full", default="")
+    ap.add_argument("--save-components", default="", help="npy: the count-normalised components by add depth, mean over the inputs (tools/cornell_mc.py)")
     a = ap.parse_args()
     import cornell_offsets as co
     from oracle import oracle
@@ -89,6 +90,8 @@ def main():
             m = reg == ids[inst]
             print(f"  {nm:9s} add at bounce {dd}: raw R " + " ".join(f"{r[dd][m][:, 0].mean():.5f}" for r in raw) + "   / count: " + " ".join(f"{e[dd][m][:, 0].mean():.5f}" for e in E))
     E = np.mean(E, axis=0)
+    if a.save_components:
+        np.save(a.save_components, E)
     N = 5000
     m = (reg >= 0)[..., None] & (rene < 0.9) & (rene > 0.01) & ((reg >> 12) != 7)[..., None]
     groups = [[1], [2], [3], [4], [5], [6, 7, 8, 9]]
