@@ -270,3 +270,37 @@ def test_image_map_repeats_over_many_periods(oracle_mod):
         aov_check(g[2], o[2], atol=6e-3 * 4, frac=2e-2)
         assert abs(float(g[2].mean()) - float(o[2].mean())) <= 2e-3 * float(o[2].mean())
         t1_check(g[0], o[0], frac=2e-2, relmse=1e-3)
+
+
+@pytest.mark.parametrize("name", ["cornell", "dragon"])
+def test_tile_shards_of_a_ragged_image_clear_and_add_their_chains_over_the_owned_tiles_only(name):
+    """Round 4: a tile shard's eight frame chains hold something in the tiles it owns only, so rene_reset clears and the hand-out adds the
+    chains over those tiles alone (kernels.hip, chains_tiles_kernel).  On an image whose size is no multiple of the 32 x 32 tile (partial
+    tiles at the right and bottom edges), with three ranks: a job rendered AFTER another job and a reset equals the same job on a fresh
+    context bit for bit (nothing of the first job survives in any chain), nothing is written outside the owned tiles, and the ranks'
+    images add up to the unsharded one bit for bit."""
+    s = scenes.cornell_box(100, 70) if name == "cornell" else scenes.dragon_class(100, 70, 24, 26)
+    with api.Renderer(s) as r:
+        r.render(0, 11)
+        whole = [r.download(l) for l in range(3)]
+    acc = [np.zeros_like(w) for w in whole]
+    for rank in range(3):
+        with api.Renderer(s, shard_mode=abi.SHARD_TILES, shard_rank=rank, shard_count=3) as r:
+            r.render(5, 9)          # another job first ...
+            r.sync()
+            r.reset()               # ... cleared over the owned tiles
+            r.render(0, 4)
+            r.download(1)           # (a hand-out in the middle of the job)
+            r.render(4, 7)
+            got = [r.download(l) for l in range(3)]
+        with api.Renderer(s, shard_mode=abi.SHARD_TILES, shard_rank=rank, shard_count=3) as f:
+            f.render(0, 11)
+            for l in range(3):
+                assert np.array_equal(got[l], f.download(l)), (rank, l)
+        ys, xs = np.nonzero(np.abs(got[1]).sum(axis=2) > 0)  # layer 1: first-hit normals, non-zero wherever the camera ray hit something
+        tiles = (ys // 32) * ((100 + 31) // 32) + xs // 32
+        assert (tiles % 3 == rank).all(), rank
+        for l in range(3):
+            acc[l] += got[l]
+    for l in range(3):
+        assert np.array_equal(acc[l], whole[l]), l
