@@ -573,6 +573,13 @@ def main():
                           f"(frames 0-{args.cpu_spp - 1}), {so.rays} rays in {dt:.1f} s",
                 "algorithmic_bytes_per_ray": abi.algorithmic_bytes(so) / max(1, so.rays),
             }
+        # the line's last key, so that a reader who keeps only its tail still has every number that matters: the headline and, compactly, the others
+        out["summary"] = {"Mrays/s": round(out["value"], 1), "n_gpus": n_gpus, "ms_per_step": round(out["ms_per_step"], 3),
+                          "roofline_frac": out["roofline"]["frac"], "useful_lane_frac": out["roofline"]["useful_lane_frac"], "pmc_stale": out["roofline"]["pmc_stale"],
+                          "other_configs [Mrays/s, valu frac, useful lanes]": out["config"].get("other_configs"),
+                          "multi_gpu_configs Mrays/s": ({k: (round(v["value"], 1) if isinstance(v, dict) and v.get("value") else None) for k, v in multi_configs.items()}
+                                                        if multi_configs is not None else None),
+                          "cpu_baseline Mrays/s": (out.get("cpu_baseline") or {}).get("value")}
         print(json.dumps(out), flush=True)
     try:
         r.close()
